@@ -1,0 +1,135 @@
+/* rgp_hip.h -- C ABI of librgp_hip.so: the MI355X (gfx950) implementation of the recurrent-GP variational
+ * inference hot path (per-layer ARD-RBF K_uu, psi0/psi1/psi2 statistics over lagged latent windows, the M x M
+ * Cholesky/Woodbury algebra of the collapsed / SVI bound, all gradients, and the window scatter-add).
+ *
+ * The reference (zhenwendai/RGP) is pure Python with NO FFI; its seams are duck-typed Python protocols
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces.  A maintainer of the
+ * reference would bind these with ctypes from autoreg/layers.py (stub in INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain C linkage, POD structs, no exceptions; every call returns rgp_status (0 = ok);
+ *  - every pointer inside rgp_layer_in/out and every "dev" pointer is a DEVICE pointer to row-major fp64
+ *    (or int64 where stated) owned by the caller; the library owns only its opaque workspace;
+ *  - all work is enqueued on the stream given to rgp_create; no call synchronises except rgp_sync_status;
+ *  - a handle is not thread-safe; handles on different devices/ranks are independent;
+ *  - a non-positive-definite K_uu / q(U) covariance does NOT get GPy's silent jitter retry (jitchol): the step
+ *    finishes with NaNs and rgp_sync_status reports RGP_ERR_NOT_PD with the failing pivot index.
+ */
+#ifndef RGP_HIP_H
+#define RGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rgp_ctx* rgp_handle;
+typedef int rgp_status;
+
+enum {
+  RGP_OK = 0,
+  RGP_ERR_BAD_ARG = 1,      /* shape / mode outside what this build supports (message in rgp_last_error) */
+  RGP_ERR_HIP = 2,          /* a HIP runtime call failed */
+  RGP_ERR_NOT_PD = 3,       /* Cholesky met a non-positive pivot (index in rgp_sync_status's pivot output) */
+  RGP_ERR_WORKSPACE = 4     /* workspace allocation failed */
+};
+
+enum { RGP_MODE_VARDTC = 0, RGP_MODE_SVI = 1 };
+
+/* Geometry + inputs of one sparse-GP layer evaluated on a minibatch of sequences.
+ * Row n of sequence s has inputs   [ own[n .. n+X_win)  |  up[u_off+n .. u_off+n+U_win) ]   (time-major then
+ * dimension, right aligned: u_off = up_len[s] - N_s - U_win + 1, N_s = own_len[s] - X_win) and target own[X_win+n]
+ * -- the window rule of autoreg/layers.py:1399-1431 (Layer._update_conv/_update_X), kept implicit (never copied by
+ * the caller). */
+typedef struct {
+  int32_t M, D;             /* inducing points; output width (= X_dim for hidden layers, D_y for the observed layer) */
+  int32_t X_win, X_dim;     /* own-history window (0 = not autoregressive) and width of the own signal */
+  int32_t U_win, U_dim;     /* input window and width (latent of the layer above, or the controls for the top layer) */
+  int32_t n_seq;            /* sequences in this call (minibatch) */
+  int32_t mode;             /* RGP_MODE_VARDTC (vardtc.py:88) or RGP_MODE_SVI (svi_vardtc.py:70) */
+  int32_t y_uncertain;      /* 1: hidden layer, outputs are q(x) rows >= X_win with variances (own_var != NULL) */
+  int32_t reserved;
+  int64_t N;                /* total data rows of the call = sum_s (own_len[s] - X_win) */
+  int64_t own_rows;         /* sum_s own_len[s] */
+  int64_t up_rows;          /* sum_s up_len[s] (0 when U_win == 0) */
+  double  qU_ratio;         /* n_batch / n_total (layers.py:328); multiplies KL(q(U)||p(U)) */
+  double  up_var_const;     /* used when up_var == NULL (controls: 1e-10, model.py:669) */
+  /* per-sequence tables, int64[n_seq] on the device: *_off = ELEMENT offset of the sequence's first row from the
+   * signal's base pointer (so several signals may live in one flat parameter buffer), *_len = number of rows */
+  const int64_t *own_off, *own_len, *up_off, *up_len;
+  /* signals */
+  const double *own_mean, *own_var;   /* hidden: latent mean/var store; observed: Y and NULL */
+  const double *up_mean, *up_var;
+  /* global parameters (device; scalars are 1-element arrays so no host sync is needed) */
+  const double *Z;          /* M x Q,  Q = X_win*X_dim + U_win*U_dim */
+  const double *variance;   /* kern.variance      (sigma_f^2) */
+  const double *inv_l;      /* kern.inv_l [Q]     (1/lengthscale^2, GPy RBF(ARD=True, inv_l=True)) */
+  const double *noise;      /* likelihood.variance */
+  const double *qU_m;       /* SVI: M x D */
+  const double *qU_W;       /* SVI: M x M, q(U) covariance = W W^T + a I (layers.py:71) */
+  const double *qU_a;       /* SVI: scalar */
+} rgp_layer_in;
+
+/* Outputs of one layer step: what SparseGP_MPI._inference_vardtc (layers.py:66-176), Layer._update_qX_gradients
+ * (:1452), Layer._prepare_gradients (:1460) and Layer.update_latent_gradients (:1433) leave behind. */
+typedef struct {
+  double *elbo;             /* [1]: logL - qU_ratio*KL + entropy/prior terms of this layer's own latent */
+  double *gZ, *gvariance, *ginv_l, *gnoise;        /* M x Q, [1], [Q], [1] */
+  double *gqU_m, *gqU_W, *gqU_a;                   /* SVI only */
+  double *g_own_mean, *g_own_var;   /* hidden layers: WRITTEN (=) for the rows of the sequences in the call; same layout
+                                       as own_mean/own_var */
+  double *g_up_mean, *g_up_var;     /* ACCUMULATED (+=), same layout as up_mean/up_var; NULL for the top layer
+                                       (controls are data, layers.py:1462-1465) */
+  double *woodbury_inv, *woodbury_vector;          /* M x M, M x D (posterior for prediction); may be NULL */
+} rgp_layer_out;
+
+/* ---- lifecycle --------------------------------------------------------------------------------------------- */
+rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream);
+void       rgp_destroy(rgp_handle h);
+const char* rgp_last_error(rgp_handle h);
+int        rgp_abi_version(void);
+/* Blocks until the handle's stream is idle; returns RGP_ERR_NOT_PD / RGP_ERR_HIP if any step since the last call
+ * failed.  pivot (may be NULL) receives the failing Cholesky column. */
+rgp_status rgp_sync_status(rgp_handle h, int* pivot);
+/* Upper bound of the workspace (bytes) a layer step of this geometry needs; the workspace grows on demand. */
+int64_t    rgp_workspace_bytes(int64_t N, int M, int Q, int D);
+
+/* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,
+ *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
+rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);
+
+/* ---- unit-testable pieces (dense, caller-materialised X; replace the GPy kernel protocol) -------------------- */
+/* kern.K(Z) + jitter*I (vardtc.py:110-114). */
+rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,
+                   double jitter, double* Kuu);
+/* kern.psi1(Z, q(X)) -> N x M and kern.psi2(Z, q(X)) -> M x M (vardtc.py:60-61); either output may be NULL. */
+rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
+                           const double* variance, const double* inv_l, double* psi1, double* psi2);
+/* kern.update_gradients_expectations + gradients_Z_expectations + gradients_qX_expectations (layers.py:98-132,
+ * 1452-1458) for given dL_dpsi1 (N x M, may be NULL) and dL_dpsi2 (M x M, may be NULL); dL_dpsi0 enters as its sum.
+ * Outputs: dvar[1], dinv_l[Q], dZ[M x Q], dmu[N x Q], dS[N x Q]. */
+rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
+                            const double* variance, const double* inv_l, double dL_dpsi0_sum, const double* dL_dpsi1,
+                            const double* dL_dpsi2, double* dvar, double* dinv_l, double* dZ, double* dmu, double* dS);
+/* The M x M algebra of SVI_VarDTC.inference + comp_KL_qU (svi_vardtc.py:70-215) given the statistics.
+ * psi1Y is D x M (= Y^T psi1, unscaled), yry = sum(Ymean^2)+sum(Yvar).  Outputs (any may be NULL):
+ * logL_minus_KL[1], dL_dKmm (M x M, includes -ratio*dKL_dKuu), dL_dpsi2 (M x M), Kinv_mu (M x D),
+ * dL_dthetaL[1], gqU_m (M x D), gqU_W (M x M), gqU_a[1], woodbury_inv (M x M). */
+rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, double qU_ratio, const double* Kuu_jit,
+                         const double* noise, const double* qU_m, const double* qU_W, const double* qU_a,
+                         const double* psi0sum, const double* psi1Y, const double* psi2, const double* yry,
+                         double* logL_minus_KL, double* dL_dKmm, double* dL_dpsi2, double* Kinv_mu,
+                         double* dL_dthetaL, double* gqU_m, double* gqU_W, double* gqU_a, double* woodbury_inv);
+
+/* ---- optimiser step on device (the outer SVI loop's Adam; positive parameters live in softplus space) -------- */
+/* x, m, v: n doubles of optimiser-space parameter and Adam moments; g: gradient w.r.t. the CONSTRAINED value p;
+ * positive[i] != 0 -> p = softplus(x) and the chain factor 1-exp(-p) is applied (paramz Logexp).  The new constrained
+ * values are written to p.  Maximises (gradient ASCENT on the ELBO).  step is the 1-based Adam step count. */
+rgp_status rgp_adam_step(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,
+                         const uint8_t* positive, double lr, double beta1, double beta2, double eps, int64_t step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGP_HIP_H */

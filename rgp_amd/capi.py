@@ -1,0 +1,116 @@
+"""Thin tensor-level wrapper over the C ABI (rgp_amd/_lib.py).  torch is used only to own device memory and to
+name the stream; every call below hands raw pointers to librgp_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import LayerIn, LayerOut, RgpError
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'librgp_hip needs contiguous device tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk64(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.dtype == torch.float64, 'fp64 only'
+
+
+class Handle(object):
+    """One handle per device/rank; all work is enqueued on the torch stream that was current at construction."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('rgp_amd needs a GPU: the hot path has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        st = self.lib.rgp_create(C.byref(h), self.device.index, C.c_void_p(self.stream.cuda_stream))
+        if st != 0:
+            raise RgpError(st, 'rgp_create failed')
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.rgp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise RgpError(st, self.lib.rgp_last_error(self.h).decode())
+
+    def sync(self):
+        """Synchronise and raise if a Cholesky failed since the last call (no jitter retry, see rgp_hip.h)."""
+        piv = C.c_int(0)
+        self._check(self.lib.rgp_sync_status(self.h, C.byref(piv)))
+
+    def new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def scalar(self, v):
+        return torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+
+    # ---- unit pieces ---------------------------------------------------------------------------------------------
+    def kuu(self, Z, variance, inv_l, jitter=1e-6):
+        _chk64(Z, variance, inv_l)
+        M, Q = Z.shape
+        out = self.new(M, M)
+        self._check(self.lib.rgp_kuu(self.h, M, Q, _p(Z), _p(variance), _p(inv_l), jitter, _p(out)))
+        return out
+
+    def psi_forward(self, mu, S, Z, variance, inv_l, want_psi1=True, want_psi2=True):
+        _chk64(mu, S, Z, variance, inv_l)
+        N, Q = mu.shape
+        M = Z.shape[0]
+        p1 = self.new(N, M) if want_psi1 else None
+        p2 = self.new(M, M) if want_psi2 else None
+        self._check(self.lib.rgp_psi_forward(self.h, N, M, Q, _p(mu), _p(S), _p(Z), _p(variance), _p(inv_l), _p(p1), _p(p2)))
+        return p1, p2
+
+    def psi_backward(self, mu, S, Z, variance, inv_l, dL_dpsi0_sum, dL_dpsi1, dL_dpsi2):
+        _chk64(mu, S, Z, variance, inv_l, dL_dpsi1, dL_dpsi2)
+        N, Q = mu.shape
+        M = Z.shape[0]
+        dvar, dil, dZ = self.new(1), self.new(Q), self.new(M, Q)
+        dmu, dS = self.new(N, Q), self.new(N, Q)
+        self._check(self.lib.rgp_psi_backward(self.h, N, M, Q, _p(mu), _p(S), _p(Z), _p(variance), _p(inv_l),
+                                              float(dL_dpsi0_sum), _p(dL_dpsi1), _p(dL_dpsi2), _p(dvar), _p(dil), _p(dZ),
+                                              _p(dmu), _p(dS)))
+        return dict(dvar=dvar, dinv_l=dil, dZ=dZ, dmu=dmu, dS=dS)
+
+    def svi_chain(self, N, Kuu_jit, noise, qU_m, qU_W, qU_a, psi0sum, psi1Y, psi2, yry, qU_ratio=1.0):
+        M, D = qU_m.shape
+        o = dict(bound=self.new(1), dL_dKmm=self.new(M, M), dL_dpsi2=self.new(M, M), Kinv_mu=self.new(M, D),
+                 dL_dthetaL=self.new(1), gqU_m=self.new(M, D), gqU_W=self.new(M, M), gqU_a=self.new(1),
+                 woodbury_inv=self.new(M, M))
+        self._check(self.lib.rgp_svi_chain(self.h, N, M, D, float(qU_ratio), _p(Kuu_jit), _p(noise), _p(qU_m), _p(qU_W),
+                                           _p(qU_a), _p(psi0sum), _p(psi1Y), _p(psi2), _p(yry), _p(o['bound']),
+                                           _p(o['dL_dKmm']), _p(o['dL_dpsi2']), _p(o['Kinv_mu']), _p(o['dL_dthetaL']),
+                                           _p(o['gqU_m']), _p(o['gqU_W']), _p(o['gqU_a']), _p(o['woodbury_inv'])))
+        return o
+
+    # ---- fused layer step ----------------------------------------------------------------------------------------
+    def layer_step(self, lin, lout):
+        self._check(self.lib.rgp_layer_step(self.h, C.byref(lin), C.byref(lout)))
+
+    def adam_step(self, x, p, g, m, v, positive, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+        n = x.numel()
+        self._check(self.lib.rgp_adam_step(self.h, n, _p(x), _p(p), _p(g), _p(m), _p(v),
+                                           C.c_void_p(positive.data_ptr()) if positive is not None else None,
+                                           float(lr), float(beta1), float(beta2), float(eps), int(step)))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

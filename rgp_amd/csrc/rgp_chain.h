@@ -1,0 +1,23 @@
+// rgp_chain.h -- M x M algebra of the SVI bound (rgp_chain.hip). Internal to librgp_hip.so.
+#pragma once
+#include "rgp_common.h"
+
+struct SviChain {
+  int64_t N; int M, D; double qU_ratio;
+  // inputs (device)
+  const double *Kj, *noise, *qU_m, *qU_W, *qU_a;
+  const double *psi0sum, *psi1Y, *psi2, *yry;          // stage 2 only
+  // workspace (device, carved by svi_chain_carve)
+  double *Linv, *S, *Ls, *LsInv, *E, *EEt, *B, *A, *T1, *T2, *T3, *mA, *Kinv, *Gv;
+  double *dLdpsi2, *dKmm;                               // results consumed by the psi backward / K backward
+  double *gmu, *Kinv_mu, *Cpsi1, *Ybt, *gqm;
+  double *scal, *bound, *dthetaL;
+  // optional outputs (device, caller owned; may be null)
+  double *gqU_m, *gqU_W, *gqU_a, *winv;
+  int* status;
+};
+
+size_t svi_chain_ws_doubles(int M, int D);
+void svi_chain_carve(SviChain& c, WsAlloc& ws);
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c);
+rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c);

@@ -1,0 +1,60 @@
+// rgp_common.h -- shared device helpers and the handle of librgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/rgp_hip.h"
+
+#define RGP_JITTER 1e-6   // const_jitter, autoreg/inference/vardtc.py:28, svi_vardtc.py:26
+
+static __device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Sum over the whole workgroup; result valid in every thread. `scratch` holds >= 16 doubles of LDS.
+static __device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < nw; ++i) s += scratch[i];   // fixed order -> deterministic
+  return s;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct rgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // workspace (grown on demand, never shrunk)
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  int* status = nullptr;        // device: [0] = error code, [1] = pivot
+  int num_cu = 256;
+};
+
+struct WsAlloc {           // bump allocator over the handle's workspace
+  char* base; size_t off = 0;
+  explicit WsAlloc(char* b) : base(b) {}
+  template <typename T> T* take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg);
+rgp_status rgp_ensure_ws(rgp_handle h, size_t bytes);
+
+#define RGP_HIP_CHECK(h, expr)                                                        \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)

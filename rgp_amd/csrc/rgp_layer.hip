@@ -1,0 +1,689 @@
+// rgp_layer.hip -- C ABI of librgp_hip.so and the per-layer orchestration (see include/rgp_hip.h).
+#include <math.h>
+#include <stdio.h>
+
+#include "rgp_chain.h"
+#include "rgp_psi.h"
+
+// ==================================================================================================================
+// handle
+// ==================================================================================================================
+rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+rgp_status rgp_ensure_ws(rgp_handle h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return RGP_OK;
+  if (h->ws) {
+    hipStreamSynchronize(h->stream);
+    hipFree(h->ws);
+    h->ws = nullptr; h->ws_bytes = 0;
+  }
+  bytes = bytes + bytes / 8 + (1u << 20);
+  if (hipMalloc((void**)&h->ws, bytes) != hipSuccess) return rgp_fail(h, RGP_ERR_WORKSPACE, "workspace hipMalloc failed");
+  h->ws_bytes = bytes;
+  return RGP_OK;
+}
+
+extern "C" int rgp_abi_version(void) { return 1; }
+
+extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) {
+  if (!out) return RGP_ERR_BAD_ARG;
+  rgp_ctx* h = new rgp_ctx();
+  h->device = device;
+  h->stream = (hipStream_t)hip_stream;
+  if (hipSetDevice(device) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+  if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
+  *out = h;
+  return RGP_OK;
+}
+
+extern "C" void rgp_destroy(rgp_handle h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  if (h->ws) hipFree(h->ws);
+  if (h->status) hipFree(h->status);
+  delete h;
+}
+
+extern "C" const char* rgp_last_error(rgp_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  int st[2] = {0, 0};
+  RGP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  RGP_HIP_CHECK(h, hipMemcpy(st, h->status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[0] != 0) {
+    hipMemset(h->status, 0, 2 * sizeof(int));
+    if (pivot) *pivot = st[1];
+    char buf[128];
+    snprintf(buf, sizeof(buf), "Cholesky: matrix not positive definite at column %d (no jitter retry, see rgp_hip.h)", st[1]);
+    return rgp_fail(h, (rgp_status)st[0], buf);
+  }
+  return RGP_OK;
+}
+
+// ==================================================================================================================
+// small kernels of the layer step
+// ==================================================================================================================
+// dLdpsi1[n,m] = sum_d Ym[n,d] Cpsi1[m,d];  dYm[n,d] = -beta Ym[n,d] + sum_m psi1[n,m] Cpsi1[m,d]   (svi_vardtc.py:164,192)
+__global__ void __launch_bounds__(256) svi_rows_kernel(int64_t N, int M, int D, const double* __restrict__ Ym,
+                                                        const double* __restrict__ Cpsi1, const double* __restrict__ psi1,
+                                                        const double* __restrict__ noise, double* __restrict__ dLdpsi1,
+                                                        double* __restrict__ dYm) {
+  extern __shared__ double lds[];
+  const int DS = D + 1;
+  double* cs = lds;                       // [M x DS]
+  for (int i = threadIdx.x; i < M * D; i += blockDim.x) cs[(i / D) * DS + (i % D)] = Cpsi1[i];
+  __syncthreads();
+  const double beta = 1.0 / noise[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < N; r += (int64_t)gridDim.x * wpb) {
+    const double* __restrict__ y = Ym + r * D;
+    for (int m = lane; m < M; m += 64) {
+      double acc = 0.0;
+      for (int d = 0; d < D; ++d) acc += y[d] * cs[m * DS + d];
+      dLdpsi1[r * M + m] = acc;
+    }
+    if (dYm) {
+      const double* __restrict__ p = psi1 + r * M;
+      for (int d = lane; d < D; d += 64) {
+        double acc = 0.0;
+        for (int m = 0; m < M; ++m) acc += p[m] * cs[m * DS + d];
+        dYm[r * D + d] = -beta * y[d] + acc;
+      }
+    }
+  }
+}
+
+// out partial [blk][k][p] = sum over the block's rows of A[n,k] B[n,p]        (psi1Y = Ym^T psi1, vardtc.py:83)
+#define CM_TILE 32
+#define CM_MAXK 32
+__global__ void __launch_bounds__(256) colmm_kernel(int64_t N, int K, int P, const double* __restrict__ A,
+                                                     const double* __restrict__ B, double* __restrict__ part) {
+  extern __shared__ double lds[];
+  double* a_s = lds;                          // [CM_TILE x K]
+  double* b_s = a_s + (size_t)CM_TILE * K;    // [CM_TILE x P]
+  const int G = blockDim.x / P;
+  const int p = threadIdx.x % P, g = threadIdx.x / P;
+  const bool act = g < G;
+  double acc[CM_MAXK];
+#pragma unroll
+  for (int k = 0; k < CM_MAXK; ++k) acc[k] = 0.0;
+  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+  for (int64_t rb = r0; rb < r1; rb += CM_TILE) {
+    const int nr = (int)((r1 - rb) < CM_TILE ? (r1 - rb) : CM_TILE);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * K; i += blockDim.x) a_s[i] = A[rb * K + i];
+    for (int i = threadIdx.x; i < nr * P; i += blockDim.x) b_s[i] = B[rb * P + i];
+    __syncthreads();
+    if (act) {
+      for (int r = 0; r < nr; ++r) {
+        const double b = b_s[r * P + p];
+#pragma unroll
+        for (int k = 0; k < CM_MAXK; ++k) {
+          const int kk = g + k * G;
+          if (kk < K) acc[k] += a_s[r * K + kk] * b;
+        }
+      }
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < CM_MAXK; ++k) {
+      const int kk = g + k * G;
+      if (kk < K) part[((size_t)blockIdx.x * K + kk) * P + p] = acc[k];
+    }
+  }
+}
+
+__global__ void symmetrise_kernel(int M, const double* __restrict__ A, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M * M) out[i] = 0.5 * (A[i] + A[(i % M) * M + i / M]);
+}
+
+__global__ void psi0sum_kernel(int64_t N, const double* variance, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)N * variance[0];
+}
+
+// Kernel-hyperparameter gradients: psi1 + psi2 partial sums, the Zdist factor of psi2 and the K_uu backward
+// (kern.update_gradients_full / gradients_X on dL_dKmm, layers.py:105,134).
+struct FinalizeArgs {
+  int M, Q, QP;
+  const double *Zc, *lam, *variance;
+  const double *Kj;        // K_uu + jitter I (may be null when dKmm is null)
+  const double *dKmm;      // may be null
+  const double *dLs, *psi2;  // symmetrised dL_dpsi2 and summed psi2 (may be null)
+  const double *dz1;       // [M x QP] psi1 part (may be null)
+  const double *dz2;       // [QP x 128] psi2 part, transposed layout (may be null)
+  const double *dlam1, *dlam2, *lsum1, *wsum2;    // may be null
+  double psi0_coef;        // sum_n dL_dpsi0[n]  (d psi0/d variance = 1)
+  const double* psi0_dev;  // optional device scalar c: adds c[0]*psi0_dev_scale (used for -D beta N / 2)
+  double psi0_dev_scale;
+  double *gZ, *ginv_l, *gvariance;   // [M x Q], [Q], [1]
+};
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
+  extern __shared__ double lds[];
+  __shared__ double scratch[16];
+  double* dlrow = lds;        // [M x QP]
+  const int M = a.M, Q = a.Q, QP = a.QP, t = threadIdx.x;
+  const double var = a.variance[0];
+  double gsum = 0.0;
+  for (int i = t; i < M * QP; i += blockDim.x) {
+    const int m = i / QP, q = i % QP;
+    double dz = 0.0, dl = 0.0;
+    if (q < Q) {
+      const double zm = a.Zc[m * QP + q];
+      double s1 = 0.0, s2 = 0.0;
+      for (int mp = 0; mp < M; ++mp) {
+        double gk = 0.0, gkT = 0.0, ws = 0.0;
+        if (a.dKmm) {
+          const double k1 = a.Kj[m * M + mp] - (m == mp ? RGP_JITTER : 0.0);
+          gk = a.dKmm[m * M + mp] * k1;
+          gkT = a.dKmm[mp * M + m] * k1;
+        }
+        if (a.dLs) ws = a.dLs[m * M + mp] * a.psi2[m * M + mp];
+        const double df = zm - a.Zc[mp * QP + q];
+        s1 += (gk + gkT + ws) * df;
+        s2 += (gk + 0.5 * ws) * df * df;
+      }
+      dz = -a.lam[q] * s1;
+      dl = -0.5 * s2;
+      if (a.dz1) dz += a.dz1[m * QP + q];
+      if (a.dz2) dz += a.dz2[q * RGP_PSI2_TEAM + m];
+      a.gZ[m * Q + q] = dz;
+    }
+    dlrow[i] = dl;
+  }
+  if (a.dKmm) {
+    for (int i = t; i < M * M; i += blockDim.x) {
+      const int m = i / M, mp = i % M;
+      gsum += a.dKmm[i] * (a.Kj[i] - (m == mp ? RGP_JITTER : 0.0));
+    }
+  }
+  gsum = block_sum(gsum, scratch);
+  __syncthreads();
+  if (t < Q) {
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) s += dlrow[m * QP + t];
+    if (a.dlam1) s += a.dlam1[t];
+    if (a.dlam2) s += a.dlam2[t];
+    a.ginv_l[t] = s;
+  }
+  if (t == 0) {
+    double g = a.psi0_coef + gsum / var;
+    if (a.psi0_dev) g += a.psi0_dev[0] * a.psi0_dev_scale;
+    if (a.lsum1) g += a.lsum1[0] / var;
+    if (a.wsum2) g += 2.0 * a.wsum2[0] / var;
+    a.gvariance[0] = g;
+  }
+}
+
+// -D beta N / 2 (= sum_n dL_dpsi0, svi_vardtc.py:162) as a device scalar
+__global__ void psi0_coef_kernel(int64_t N, int D, const double* noise, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = -0.5 * (double)D * (double)N / noise[0];
+}
+
+__global__ void prefix_kernel(int n_seq, const int64_t* __restrict__ len, int64_t* pre) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t acc = 0;
+    for (int s = 0; s < n_seq; ++s) { pre[s] = acc; acc += len[s]; }
+    pre[n_seq] = acc;
+  }
+}
+
+static __device__ __forceinline__ int find_seq(const int64_t* __restrict__ pre, int n_seq, int64_t r) {
+  int lo = 0, hi = n_seq;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// Gradients w.r.t. the layer's own latent (hidden layers): output-side terms + entropy/prior (layers.py:1460-1481,
+// variational.py:4-25) + the own-history part of the window scatter (layers.py:1443-1444) written as a gather so the
+// summation order is fixed.  One thread per latent element.
+struct LatentArgs {
+  WindowSpec w; int QP; int64_t own_rows;
+  const int64_t* own_pre;
+  const double *gmu, *gS, *dYm, *noise;
+  double *g_own_mean, *g_own_var, *elbo_part;
+};
+
+__global__ void __launch_bounds__(256) own_latent_kernel(LatentArgs a) {
+  __shared__ double scratch[16];
+  const int Xd = a.w.X_dim, Xw = a.w.X_win;
+  const int64_t total = a.own_rows * Xd;
+  const double beta = 1.0 / a.noise[0];
+  double el = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / Xd;
+    const int d = (int)(i % Xd);
+    const int s = find_seq(a.own_pre, a.w.n_seq, row);
+    const int64_t tt = row - a.own_pre[s];
+    const int64_t Ns = a.w.own_len[s] - Xw;
+    const int64_t gi = a.w.own_off[s] + tt * Xd + d;
+    const double mu = a.w.own_mean[gi], S = a.w.own_var[gi];
+    double gm, gv;
+    if (tt >= Xw) {
+      const int64_t r = a.w.row_off[s] + (tt - Xw);
+      gm = a.dYm[r * Xd + d];
+      gv = -0.5 * beta + 0.5 / S;                                   // svi_vardtc.py:193 + variational.py:12
+      el += 0.5 * (1.0 + 1.8378770664093453 + log(S));              // -NormalEntropy.comp_value
+    } else {
+      gm = -mu;                                                     // variational.py:23
+      gv = -0.5 * (1.0 - 1.0 / S);                                  // variational.py:24
+      el -= 0.5 * (mu * mu + S - log(S)) - 0.5;                     // -NormalPrior.comp_value
+    }
+    for (int j = 0; j < Xw; ++j) {
+      const int64_t n = tt - j;
+      if (n >= 0 && n < Ns) {
+        const int64_t r = a.w.row_off[s] + n;
+        gm += a.gmu[r * a.QP + j * Xd + d];
+        gv += a.gS[r * a.QP + j * Xd + d];
+      }
+    }
+    a.g_own_mean[gi] = gm;
+    a.g_own_var[gi] = gv;
+  }
+  const double tot = block_sum(el, scratch);
+  if (threadIdx.x == 0) a.elbo_part[blockIdx.x] = tot;
+}
+
+// Input-side part of the window scatter (layers.py:1446-1448): accumulate into the gradient of the layer above.
+struct UpArgs {
+  WindowSpec w; int QP; int64_t up_rows;
+  const int64_t* up_pre;
+  const double *gmu, *gS;
+  double *g_up_mean, *g_up_var;
+};
+
+__global__ void __launch_bounds__(256) up_latent_kernel(UpArgs a) {
+  const int Ud = a.w.U_dim, Uw = a.w.U_win, Qx = a.w.X_win * a.w.X_dim;
+  const int64_t total = a.up_rows * Ud;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / Ud;
+    const int d = (int)(i % Ud);
+    const int s = find_seq(a.up_pre, a.w.n_seq, row);
+    const int64_t tt = row - a.up_pre[s];
+    const int64_t Ns = a.w.own_len[s] - a.w.X_win;
+    const int64_t uoff = a.w.up_len[s] - Ns - Uw + 1;
+    double gm = 0.0, gv = 0.0;
+    for (int j = 0; j < Uw; ++j) {
+      const int64_t n = tt - uoff - j;
+      if (n >= 0 && n < Ns) {
+        const int64_t r = a.w.row_off[s] + n;
+        gm += a.gmu[r * a.QP + Qx + j * Ud + d];
+        gv += a.gS[r * a.QP + Qx + j * Ud + d];
+      }
+    }
+    const int64_t gi = a.w.up_off[s] + tt * Ud + d;
+    a.g_up_mean[gi] += gm;
+    a.g_up_var[gi] += gv;
+  }
+}
+
+__global__ void finish_elbo_kernel(const double* bound, const double* part, int npart, const double* dthetaL,
+                                   double* elbo, double* gnoise) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = bound[0];
+    for (int i = 0; i < npart; ++i) s += part[i];
+    elbo[0] = s;
+    if (gnoise) gnoise[0] = dthetaL[0];
+  }
+}
+
+__global__ void unpad_kernel(int64_t N, int Q, int QP, const double* __restrict__ in, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * Q) out[i] = in[(i / Q) * QP + (i % Q)];
+}
+
+__global__ void scale_psi_kernel(int64_t n, const double* variance, int power, double* x) {
+  // the row constants carry log(variance) already; nothing to do -- kept for ABI symmetry
+}
+
+// ==================================================================================================================
+// workspace carving shared by the entry points
+// ==================================================================================================================
+struct LayerWs {
+  ZTerms zt; RowTerms rt;
+  double *psi1, *Lp, *gmu, *gS, *Ym, *Yv, *dYm;
+  double *p2_part, *p2_tri, *psi2, *dLs;
+  double *dz1_part, *dz1, *dz2_part, *dz2, *dlam1_part, *dlam1, *dlam2_part, *dlam2, *lsum1_part, *lsum1, *wsum2_part, *wsum2;
+  double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part;
+  int64_t *row_off, *own_pre, *up_pre;
+  int nblk1, nblk2;
+};
+
+#define NBLK1 512          // workgroups of the psi1-side reductions
+#define LAT_BLOCKS 1024
+
+static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int D, int n_seq, LayerWs& L, SviChain* ch) {
+  WsAlloc ws(base);
+  const int QP = round_up(Q, 8);
+  const size_t nq = (size_t)N * QP, nm = (size_t)N * M, nd = (size_t)N * (D > 0 ? D : 1);
+  const int tri = M * (M + 1) / 2;
+  L.nblk1 = NBLK1;
+  L.nblk2 = (int)psi2_num_blocks(h, N);
+  L.zt.M = M; L.zt.Q = Q; L.zt.QP = QP;
+  L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP);
+  L.zt.zd = ws.take<double>((size_t)M * M); L.zt.Kuu = ws.take<double>((size_t)M * M);
+  L.rt.N = N; L.rt.QP = QP;
+  L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq);
+  L.rt.g0 = ws.take<double>(N); L.rt.g1 = ws.take<double>(N);
+  L.psi1 = ws.take<double>(nm); L.Lp = ws.take<double>(nm);
+  L.gmu = ws.take<double>(nq); L.gS = ws.take<double>(nq);
+  L.Ym = ws.take<double>(nd); L.Yv = ws.take<double>(nd); L.dYm = ws.take<double>(nd);
+  L.p2_part = ws.take<double>((size_t)L.nblk2 * tri); L.p2_tri = ws.take<double>(tri);
+  L.psi2 = ws.take<double>((size_t)M * M); L.dLs = ws.take<double>((size_t)M * M);
+  L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
+  L.dz2_part = ws.take<double>((size_t)L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
+  L.dlam1_part = ws.take<double>((size_t)L.nblk1 * QP); L.dlam1 = ws.take<double>(QP);
+  L.dlam2_part = ws.take<double>((size_t)L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
+  L.lsum1_part = ws.take<double>(L.nblk1); L.lsum1 = ws.take<double>(1);
+  L.wsum2_part = ws.take<double>(L.nblk2); L.wsum2 = ws.take<double>(1);
+  L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
+  L.psi1Y_part = ws.take<double>((size_t)L.nblk1 * (D > 0 ? D : 1) * M); L.psi1Y = ws.take<double>((size_t)(D > 0 ? D : 1) * M);
+  L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
+  L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
+  if (ch) svi_chain_carve(*ch, ws);
+  return ws.off;
+}
+
+extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
+  rgp_ctx tmp;
+  LayerWs L;
+  SviChain ch{}; ch.M = M; ch.D = D > 0 ? D : 1;
+  return (int64_t)carve_layer(&tmp, nullptr, N, M, Q, D, 4096, L, &ch);
+}
+
+static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
+  if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
+  if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is not supported by this build");
+  if (round_up(Q, 8) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
+  return RGP_OK;
+}
+
+static rgp_status last_launch(rgp_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return RGP_OK;
+}
+
+// ==================================================================================================================
+// unit entry points
+// ==================================================================================================================
+extern "C" rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,
+                              double jitter, double* Kuu) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_status st = check_geometry(h, 1, M, Q);
+  if (st) return st;
+  LayerWs L;
+  const size_t need = carve_layer(h, nullptr, 1, M, Q, 1, 1, L, nullptr);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  carve_layer(h, h->ws, 1, M, Q, 1, 1, L, nullptr);
+  launch_prep_z(h->stream, M, Q, L.zt.QP, Z, variance, inv_l, jitter, L.zt);
+  RGP_HIP_CHECK(h, hipMemcpyAsync(Kuu, L.zt.Kuu, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return last_launch(h, "rgp_kuu");
+}
+
+extern "C" rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S,
+                                      const double* Z, const double* variance, const double* inv_l, double* psi1,
+                                      double* psi2) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_status st = check_geometry(h, N, M, Q);
+  if (st) return st;
+  LayerWs L;
+  const size_t need = carve_layer(h, nullptr, N, M, Q, 1, 1, L, nullptr);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  carve_layer(h, h->ws, N, M, Q, 1, 1, L, nullptr);
+  hipStream_t s = h->stream;
+  launch_prep_z(s, M, Q, L.zt.QP, Z, variance, inv_l, RGP_JITTER, L.zt);
+  launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
+  if (psi1) launch_psi1_fwd(s, N, M, L.zt, L.rt, psi1);
+  if (psi2) {
+    Psi2Out o{};
+    o.p2_part = L.p2_part;
+    if ((st = launch_psi2(h, true, false, N, M, Q, L.zt, L.rt, nullptr, o, L.nblk2))) return st;
+    const int tri = M * (M + 1) / 2;
+    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_unpack_tri(s, M, L.p2_tri, psi2);
+  }
+  return last_launch(h, "rgp_psi_forward");
+}
+
+extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S,
+                                       const double* Z, const double* variance, const double* inv_l,
+                                       double dL_dpsi0_sum, const double* dL_dpsi1, const double* dL_dpsi2, double* dvar,
+                                       double* dinv_l, double* dZ, double* dmu, double* dS) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_status st = check_geometry(h, N, M, Q);
+  if (st) return st;
+  LayerWs L;
+  const size_t need = carve_layer(h, nullptr, N, M, Q, 1, 1, L, nullptr);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  carve_layer(h, h->ws, N, M, Q, 1, 1, L, nullptr);
+  hipStream_t s = h->stream;
+  const int QP = L.zt.QP;
+  launch_prep_z(s, M, Q, QP, Z, variance, inv_l, RGP_JITTER, L.zt);
+  launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
+  if (dL_dpsi1) {
+    launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
+    launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, dL_dpsi1, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
+    launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
+    launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
+    launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
+    launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+  } else {
+    RGP_HIP_CHECK(h, hipMemsetAsync(L.gmu, 0, (size_t)N * QP * sizeof(double), s));
+    RGP_HIP_CHECK(h, hipMemsetAsync(L.gS, 0, (size_t)N * QP * sizeof(double), s));
+  }
+  if (dL_dpsi2) {
+    hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
+    Psi2Out o{};
+    o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
+    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
+    if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
+    const int tri = M * (M + 1) / 2;
+    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_unpack_tri(s, M, L.p2_tri, L.psi2);
+    launch_reduce(s, L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+  }
+  FinalizeArgs f{};
+  f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = variance;
+  f.Kj = nullptr; f.dKmm = nullptr;
+  f.dLs = dL_dpsi2 ? L.dLs : nullptr; f.psi2 = dL_dpsi2 ? L.psi2 : nullptr;
+  f.dz1 = dL_dpsi1 ? L.dz1 : nullptr; f.dz2 = dL_dpsi2 ? L.dz2 : nullptr;
+  f.dlam1 = dL_dpsi1 ? L.dlam1 : nullptr; f.dlam2 = dL_dpsi2 ? L.dlam2 : nullptr;
+  f.lsum1 = dL_dpsi1 ? L.lsum1 : nullptr; f.wsum2 = dL_dpsi2 ? L.wsum2 : nullptr;
+  f.psi0_coef = dL_dpsi0_sum; f.psi0_dev = nullptr; f.psi0_dev_scale = 0.0;
+  f.gZ = dZ; f.ginv_l = dinv_l; f.gvariance = dvar;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), (size_t)M * QP * sizeof(double), s, f);
+  const int64_t nq = N * Q;
+  hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, N, Q, QP, L.gmu, dmu);
+  hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, N, Q, QP, L.gS, dS);
+  return last_launch(h, "rgp_psi_backward");
+}
+
+extern "C" rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, double qU_ratio, const double* Kuu_jit,
+                                    const double* noise, const double* qU_m, const double* qU_W, const double* qU_a,
+                                    const double* psi0sum, const double* psi1Y, const double* psi2, const double* yry,
+                                    double* logL_minus_KL, double* dL_dKmm, double* dL_dpsi2, double* Kinv_mu,
+                                    double* dL_dthetaL, double* gqU_m, double* gqU_W, double* gqU_a, double* woodbury_inv) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_status st;
+  SviChain c{};
+  c.N = N; c.M = M; c.D = D; c.qU_ratio = qU_ratio;
+  const size_t need = svi_chain_ws_doubles(M, D) * sizeof(double) + 64 * 256;
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  WsAlloc ws(h->ws);
+  svi_chain_carve(c, ws);
+  c.Kj = Kuu_jit; c.noise = noise; c.qU_m = qU_m; c.qU_W = qU_W; c.qU_a = qU_a;
+  c.psi0sum = psi0sum; c.psi1Y = psi1Y; c.psi2 = psi2; c.yry = yry;
+  c.gqU_m = gqU_m; c.gqU_W = gqU_W; c.gqU_a = gqU_a; c.winv = woodbury_inv; c.status = h->status;
+  if ((st = launch_svi_chain_pre(h, c))) return st;
+  if ((st = launch_svi_chain_post(h, c))) return st;
+  hipStream_t s = h->stream;
+  const size_t mm = (size_t)M * M * sizeof(double), md = (size_t)M * D * sizeof(double);
+  if (logL_minus_KL) RGP_HIP_CHECK(h, hipMemcpyAsync(logL_minus_KL, c.bound, sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (dL_dKmm) RGP_HIP_CHECK(h, hipMemcpyAsync(dL_dKmm, c.dKmm, mm, hipMemcpyDeviceToDevice, s));
+  if (dL_dpsi2) RGP_HIP_CHECK(h, hipMemcpyAsync(dL_dpsi2, c.dLdpsi2, mm, hipMemcpyDeviceToDevice, s));
+  if (Kinv_mu) RGP_HIP_CHECK(h, hipMemcpyAsync(Kinv_mu, c.Kinv_mu, md, hipMemcpyDeviceToDevice, s));
+  if (dL_dthetaL) RGP_HIP_CHECK(h, hipMemcpyAsync(dL_dthetaL, c.dthetaL, sizeof(double), hipMemcpyDeviceToDevice, s));
+  return last_launch(h, "rgp_svi_chain");
+}
+
+// ==================================================================================================================
+// the fused layer step
+// ==================================================================================================================
+extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
+  if (!h || !in || !out) return RGP_ERR_BAD_ARG;
+  if (in->mode != RGP_MODE_SVI)
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: only RGP_MODE_SVI runs on the device in this build");
+  const int M = in->M, D = in->D;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  const int64_t N = in->N;
+  rgp_status st = check_geometry(h, N, M, Q);
+  if (st) return st;
+  if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
+  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
+  if (D > 64 * CM_MAXK) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large");
+  LayerWs L;
+  SviChain c{};
+  c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
+  const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, &c);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  carve_layer(h, h->ws, N, M, Q, D, in->n_seq, L, &c);
+  hipStream_t s = h->stream;
+  const int QP = L.zt.QP;
+
+  // tables + Z terms + rows
+  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
+  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
+  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+  WindowSpec w{};
+  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
+  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
+  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
+  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+
+  // data-independent algebra
+  c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
+  c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
+  c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv; c.status = h->status;
+  if ((st = launch_svi_chain_pre(h, c))) return st;
+
+  // psi1 side
+  launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
+  {
+    const size_t lds = (size_t)M * (D + 1) * sizeof(double);
+    int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(svi_rows_kernel, dim3((unsigned)b), dim3(256), lds, s, N, M, D, L.Ym, c.Cpsi1, L.psi1, in->noise,
+                       L.Lp /* dLdpsi1, overwritten in place by Lp below */, in->y_uncertain ? L.dYm : nullptr);
+  }
+  {
+    if (D > (256 / M) * CM_MAXK) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large for the psi1Y pass of this build");
+    const size_t lds = ((size_t)CM_TILE * D + (size_t)CM_TILE * M) * sizeof(double);
+    hipLaunchKernelGGL(colmm_kernel, dim3(L.nblk1), dim3(256), lds, s, N, D, M, L.Ym, L.psi1, L.psi1Y_part);
+    launch_reduce(s, L.nblk1, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
+  }
+  launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
+  launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
+  launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
+  launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
+  launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+
+  // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
+  hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
+  {
+    Psi2Out o{};
+    o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
+    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
+    if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
+    const int tri = M * (M + 1) / 2;
+    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_unpack_tri(s, M, L.p2_tri, L.psi2);
+    launch_reduce(s, L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+  }
+  hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
+  hipLaunchKernelGGL(psi0_coef_kernel, dim3(1), dim3(64), 0, s, N, D, in->noise, L.psi0coef);
+
+  // data-dependent algebra, kernel-hyperparameter gradients
+  if ((st = launch_svi_chain_post(h, c))) return st;
+  {
+    FinalizeArgs f{};
+    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
+    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
+    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
+    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), (size_t)M * QP * sizeof(double), s, f);
+  }
+
+  // latent gradients
+  int npart = 0;
+  if (in->y_uncertain) {
+    LatentArgs a{};
+    a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
+    a.noise = in->noise; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var; a.elbo_part = L.elbo_part;
+    hipLaunchKernelGGL(own_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+    npart = LAT_BLOCKS;
+  }
+  if (out->g_up_mean && in->U_win > 0) {
+    UpArgs a{};
+    a.w = w; a.QP = QP; a.up_rows = in->up_rows; a.up_pre = L.up_pre; a.gmu = L.gmu; a.gS = L.gS;
+    a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
+    hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
+                     out->gnoise);
+  if (out->woodbury_vector)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.Kinv_mu, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return last_launch(h, "rgp_layer_step");
+}
+
+// ==================================================================================================================
+// Adam on optimiser-space parameters (softplus for positive ones, paramz Logexp)
+// ==================================================================================================================
+__global__ void __launch_bounds__(256) adam_kernel(int64_t n, double* __restrict__ x, double* __restrict__ p,
+                                                    const double* __restrict__ g, double* __restrict__ m,
+                                                    double* __restrict__ v, const uint8_t* __restrict__ positive, double lr,
+                                                    double b1, double b2, double eps, double c1, double c2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool pos = positive && positive[i];
+  double gi = g[i];
+  if (pos) gi *= -expm1(-p[i]);                   // d softplus(x)/dx = 1 - exp(-p)
+  const double mi = b1 * m[i] + (1.0 - b1) * gi;
+  const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const double xi = x[i] + lr * (mi / c1) / (sqrt(vi / c2) + eps);     // ascent on the ELBO
+  x[i] = xi;
+  p[i] = pos ? (xi > 36.0 ? xi : log1p(exp(xi))) : xi;
+}
+
+extern "C" rgp_status rgp_adam_step(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,
+                                    const uint8_t* positive, double lr, double beta1, double beta2, double eps,
+                                    int64_t step) {
+  if (!h || n <= 0) return RGP_ERR_BAD_ARG;
+  const double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, x, p, g, m, v, positive,
+                     lr, beta1, beta2, eps, c1, c2);
+  return last_launch(h, "rgp_adam_step");
+}

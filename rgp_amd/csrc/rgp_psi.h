@@ -1,0 +1,68 @@
+// rgp_psi.h -- launchers of the psi-statistic kernels (rgp_psi.hip). Internal to librgp_hip.so.
+#pragma once
+#include "rgp_common.h"
+
+#define RGP_PSI2_TEAM 128          // threads per workgroup of the psi2 kernel (one inducing row per thread)
+#define RGP_MAX_M 128
+#define RGP_MAX_QP 64
+
+// Z-derived, data-independent quantities of one layer.
+struct ZTerms {
+  int M, Q, QP;
+  double* c;      // [QP]  column mean of Z (shift; the bound is translation invariant)
+  double* lam;    // [QP]  inv_l padded with zeros
+  double* Zc;     // [M x QP]  Z - c, zero padded
+  double* zd;     // [M x M]   -1/4 sum_q lam_q (z_mq - z_m'q)^2
+  double* Kuu;    // [M x M]   variance*exp(-1/2 r^2) + jitter*I
+};
+
+// Row-derived quantities (one row = one lagged window).
+struct RowTerms {
+  int64_t N; int QP;
+  double* Xmu;    // [N x QP]  window means minus c, zero padded
+  double* d2;     // [N x QP]  1/(2S + l^2) = lam/(1+2 S lam)
+  double* e1;     // [N x QP]  1/(S + l^2)
+  double* g0;     // [N]  log(var^2) - 1/2 sum log(1+2 S lam) - sum d2 mu^2       (psi2 row constant)
+  double* g1;     // [N]  log(var)   - 1/2 sum log(1+S lam)                        (psi1 row constant)
+};
+
+struct WindowSpec {     // implicit lagged windows (rgp_layer_in)
+  int n_seq, X_win, X_dim, U_win, U_dim, D, y_uncertain;
+  const int64_t *own_off, *own_len, *up_off, *up_len;
+  const int64_t* row_off;             // [n_seq+1] prefix sums of N_s (device)
+  const double *own_mean, *own_var, *up_mean, *up_var;
+  double up_var_const;
+};
+
+size_t psi2_num_blocks(rgp_handle h, int64_t N);
+
+void launch_prep_z(hipStream_t s, int M, int Q, int QP, const double* Z, const double* variance, const double* inv_l,
+                   double jitter, const ZTerms& zt);
+void launch_row_offsets(hipStream_t s, int n_seq, int X_win, const int64_t* own_len, int64_t* row_off);
+void launch_rowprep_dense(hipStream_t s, int64_t N, int Q, const double* mu, const double* S, const double* variance,
+                          const ZTerms& zt, const RowTerms& rt);
+// windowed: also materialises Ym (N x D), Yv (N x D, if y_uncertain) and the partial sums of sum(Ym^2)+sum(Yv)
+void launch_rowprep_window(hipStream_t s, int64_t N, int Q, const WindowSpec& w, const double* variance,
+                           const ZTerms& zt, const RowTerms& rt, double* Ym, double* Yv, double* yry_out);
+void launch_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* psi1);
+// Lp = dL_dpsi1 * psi1; row gradients gmu/gS (=), partials of dinv_l [nblk x QP] and sum(Lp) [nblk]
+void launch_psi1_bwd(hipStream_t s, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt, const double* dLdpsi1,
+                     const double* psi1, double* Lp, double* gmu, double* gS, double* dlam_part, double* lsum_part,
+                     int nblk);
+// dZ partials [nblk x M x QP] of the psi1 term
+void launch_psi1_dz(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, const double* Lp,
+                    double* dz_part, int nblk);
+// fused psi2 pass: forward sum (tri-packed partials) and/or backward for given symmetric dLs (M x M)
+struct Psi2Out {
+  double* p2_part;     // [nblk x tri]           (forward)
+  double* dz_part;     // [nblk x QP x 128]      (backward; layout [q][m])
+  double* dlam_part;   // [nblk x QP]
+  double* wsum_part;   // [nblk]                  sum of all weights (for dvar)
+  double* gmu; double* gS; int accumulate;        // row gradients
+};
+rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt,
+                       const double* dLs, const Psi2Out& out, int nblk);
+// out[i] = scale * sum_g part[g*stride + i], i < len (fixed order)
+void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const double* part, double* out, double scale,
+                   int accumulate);
+void launch_unpack_tri(hipStream_t s, int M, const double* tri, double* full);

@@ -1,0 +1,495 @@
+"""Host side of the MI355X recurrent-GP path: the model object that mirrors ``autoreg.DeepAutoreg`` /
+``autoreg.DeepAutoreg_new`` (/root/reference/autoreg/model.py:632-740, :15-282) and drives librgp_hip.so.
+
+What lives where
+  * this file: data shift, latent initialisation, parameter layout, the top-down layer loop, optimiser loops;
+    all tensors are torch fp64 device tensors (torch = storage + stream + torch.distributed only);
+  * librgp_hip.so (include/rgp_hip.h): everything numerical per layer (windows, K_uu, psi statistics, M x M algebra,
+    all gradients, window scatter, entropy/prior terms, Adam).
+
+Parameter layout -- ONE flat fp64 device tensor ``param_array`` (constrained values, like paramz' param_array) and a
+mirror ``grad_array``:
+    [ global parameters of every layer, top layer first | ELBO slot | latent means | latent variances ]
+  * the global segment (+ELBO slot) is the single all-reduce bucket of data-parallel SVI;
+  * latent means / variances are grouped per SEQUENCE (for s: for hidden layer i top..1: T_{s,i} x H_i block), so the
+    local parameters of a contiguous minibatch are one contiguous range.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .capi import Handle
+from ._lib import LayerIn, LayerOut
+
+POSITIVE = ('variance', 'inv_l', 'noise', 'qU_a')
+
+
+def _softplus_inv(p):
+    return torch.where(p > 36.0, p, torch.log(torch.expm1(torch.clamp(p, max=36.0))))
+
+
+def _softplus(x):
+    return torch.where(x > 36.0, x, torch.log1p(torch.exp(torch.clamp(x, max=36.0))))
+
+
+class _Kern(object):
+    """``layer.kern`` with GPy's parameter names (RBF(ARD=True, inv_l=True)): ``variance``, ``inv_l`` (=1/lengthscale^2)."""
+
+    def __init__(self, variance, inv_l):
+        self.variance, self.inv_l = variance, inv_l
+
+    @property
+    def lengthscale(self):
+        return 1.0 / torch.sqrt(self.inv_l)
+
+
+class _Lik(object):
+    def __init__(self, variance):
+        self.variance = variance
+
+
+class LayerView(object):
+    """Named views of one layer's parameters / gradients inside the flat arrays (what ``model.layers[k]`` exposes in
+    the reference: ``.kern.variance``, ``.kern.inv_l``, ``.likelihood.variance``, ``.Z``, ``.qU_mean``, ``.qU_W``, ``.qU_a``)."""
+
+    def __init__(self, index, name, X_win, X_dim, U_win, U_dim, M, D, observed):
+        self.index, self.name = index, name
+        self.X_win, self.X_dim, self.U_win, self.U_dim, self.M, self.D = X_win, X_dim, U_win, U_dim, M, D
+        self.Q = X_win * X_dim + U_win * U_dim
+        self.X_observed = observed
+        self.slices = {}
+        self.qU_ratio = 1.0
+
+
+class DeepAutoreg(object):
+    """Deep autoregressive (recurrent) GP; constructor arguments follow autoreg.DeepAutoreg_new (model.py:28-33).
+
+    wins[0] is the observed layer's own window (must be 0, as in the reference), wins[i>0] the hidden windows;
+    ``self.layers`` is ordered top layer first like the reference's ``model.layers`` (model.py:94-109).
+    Not in this build ("next"): ``back_cstr=True`` (MLP / RNN recognition models)."""
+
+    def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10, likelihood=None,
+                 name='autoreg', kernels=None, U_pre_step=True, init='Y', inducing_init='rand', back_cstr=False,
+                 MLP_dims=None, inference_method='svi', minibatch_inference=False, mb_inf_tot_data_size=None,
+                 mb_inf_sample_idxes=None, device=None, seed=0, Zs=None):
+        if back_cstr:
+            raise NotImplementedError('back-constraints (autoreg/mlp.py, rnn_encoder.py) are outside this build (SURVEY 8f)')
+        if not U_pre_step:
+            raise NotImplementedError('U_pre_step=False')
+        assert wins[0] == 0, 'the observed layer cannot be autoregressive (as in the reference)'
+        self.name = name
+        self.handle = Handle(device)
+        self.device = self.handle.device
+        rng = np.random.default_rng(seed)
+        Ys = [Y] if isinstance(Y, np.ndarray) else list(Y)
+        Us = None if U is None else ([U] if isinstance(U, np.ndarray) else list(U))
+        self.wins, self.nLayers, self.U_win = list(wins), len(wins), U_win
+        self.svi = (inference_method == 'svi')
+        self.mode = _lib.RGP_MODE_SVI if self.svi else _lib.RGP_MODE_VARDTC
+        self.nDims = list(nDims) if nDims is not None else [Ys[0].shape[1]] + [1] * (self.nLayers - 1)
+        # a1: shift (model.py:53-69)
+        if Us is not None:
+            assert len(Us) == len(Ys)
+            Us = [np.asarray(u, dtype=np.float64)[:-1] for u in Us]
+            Ys = [np.asarray(y, dtype=np.float64)[U_win:] for y in Ys]
+        else:
+            Ys = [np.asarray(y, dtype=np.float64) for y in Ys]
+        self.nSeq = len(Ys)
+        self.n_total = self.nSeq if mb_inf_tot_data_size is None else int(mb_inf_tot_data_size)
+        self.Ly = np.array([y.shape[0] for y in Ys], dtype=np.int64)
+        self.Dy = Ys[0].shape[1]
+        self.Du = Us[0].shape[1] if Us is not None else 0
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.Ycat = torch.tensor(np.concatenate(Ys, 0), **f64).contiguous()
+        self.y_off = np.concatenate([[0], np.cumsum(self.Ly[:-1] * self.Dy)]).astype(np.int64)
+        if Us is not None:
+            self.Ucat = torch.tensor(np.concatenate(Us, 0), **f64).contiguous()
+            self.u_len = np.array([u.shape[0] for u in Us], dtype=np.int64)
+            self.u_off = np.concatenate([[0], np.cumsum(self.u_len[:-1] * self.Du)]).astype(np.int64)
+        else:
+            self.Ucat = None
+        # ---- layers (top first) ----
+        if not isinstance(num_inducing, (list, tuple)):
+            num_inducing = [num_inducing] * self.nLayers
+        self.order = list(range(self.nLayers - 1, -1, -1))
+        self.layers = []
+        for i in self.order:
+            top = (i == self.nLayers - 1)
+            X_win, X_dim = self.wins[i], self.nDims[i]
+            if top:
+                Uw, Ud = (U_win, self.Du) if Us is not None else (0, 0)
+            else:
+                Uw, Ud = self.wins[i + 1], self.nDims[i + 1]
+            self.layers.append(LayerView(i, 'layer_%d' % i, X_win, X_dim, Uw, Ud, int(num_inducing[i]), self.nDims[i], i == 0))
+        # ---- flat layout ----
+        off = 0
+        for L in self.layers:
+            spec = [('Z', (L.M, L.Q)), ('variance', (1,)), ('inv_l', (L.Q,)), ('noise', (1,))]
+            if self.svi:
+                spec += [('qU_m', (L.M, L.D)), ('qU_W', (L.M, L.M)), ('qU_a', (1,))]
+            for nm, shp in spec:
+                n = int(np.prod(shp))
+                L.slices[nm] = (off, off + n, shp)
+                off += n
+        self.n_global = off
+        self.elbo_slot = off
+        off += 1
+        self.loc0 = off
+        # latent blocks: element offsets relative to the start of the means region
+        self.lat_len = {i: self.Ly + self.wins[i] for i in range(1, self.nLayers)}
+        self.lat_off = {i: np.zeros(self.nSeq, dtype=np.int64) for i in range(1, self.nLayers)}
+        self.seq_loc_off = np.zeros(self.nSeq + 1, dtype=np.int64)
+        o = 0
+        for s in range(self.nSeq):
+            self.seq_loc_off[s] = o
+            for i in range(self.nLayers - 1, 0, -1):
+                self.lat_off[i][s] = o
+                o += int(self.lat_len[i][s]) * self.nDims[i]
+        self.seq_loc_off[self.nSeq] = o
+        self.n_local = o
+        self.n_param = self.loc0 + 2 * self.n_local
+        self.param_array = torch.zeros(self.n_param, **f64)
+        self.grad_array = torch.zeros(self.n_param, **f64)
+        pos = torch.zeros(self.n_param, dtype=torch.uint8, device=dev)
+        for L in self.layers:
+            for nm in POSITIVE:
+                if nm in L.slices:
+                    a, b, _ = L.slices[nm]
+                    pos[a:b] = 1
+        pos[self.loc0 + self.n_local:] = 1
+        self.positive = pos
+        self.means = self.param_array[self.loc0:self.loc0 + self.n_local]
+        self.vars = self.param_array[self.loc0 + self.n_local:]
+        self.gmeans = self.grad_array[self.loc0:self.loc0 + self.n_local]
+        self.gvars = self.grad_array[self.loc0 + self.n_local:]
+        # ---- a2: hidden q(X) initialisation (model.py:129-156) ----
+        means = np.zeros(self.n_local)
+        for i in range(1, self.nLayers):
+            H, w = self.nDims[i], self.wins[i]
+            for s in range(self.nSeq):
+                T = int(self.lat_len[i][s])
+                blk = np.zeros((T, H))
+                if init == 'Y':
+                    blk[w:] = Ys[s][:, :H]
+                elif init == 'rand':
+                    blk[:] = rng.standard_normal(blk.shape)
+                elif init == 'zero':
+                    blk[:] = rng.standard_normal(blk.shape) * 0.01
+                else:
+                    raise ValueError(init)
+                means[self.lat_off[i][s]:self.lat_off[i][s] + T * H] = blk.ravel()
+        self.means.copy_(torch.tensor(means, **f64))
+        self.vars.fill_(X_variance)
+        # ---- global parameter initialisation (layers.py:1332-1345, :51-58; model.py:94-109) ----
+        for L in self.layers:
+            i = L.index
+            Xm = self._host_X_mean(i, Ys, Us, means)
+            if Zs is not None:
+                Z = np.asarray(Zs[i], dtype=np.float64)
+            elif inducing_init == 'kmeans':
+                from sklearn.cluster import KMeans
+                km = KMeans(n_clusters=L.M, n_init=1000, max_iter=100)       # layers.py:1335
+                km.fit(Xm.copy())
+                Z = km.cluster_centers_.copy()
+            else:
+                Z = rng.standard_normal((L.M, L.Q))                            # layers.py:1339
+            self.set_param(L, 'Z', Z)
+            if kernels is not None and kernels[i] is not None:
+                kv, kil = kernels[i]
+                self.set_param(L, 'variance', kv)
+                self.set_param(L, 'inv_l', kil)
+            else:
+                self.set_param(L, 'variance', 1.0)
+                self.set_param(L, 'inv_l', np.ones(L.Q))
+            self.set_param(L, 'noise', 1.0 if i == 0 else 0.01)               # model.py:96-109
+            if self.svi:
+                from scipy.linalg import lstsq
+                Ym = np.concatenate(Ys, 0) if i == 0 else self._host_Y_mean(i, means)
+                W = lstsq(Xm, Ym)[0]                                          # util.py:32-38
+                self.set_param(L, 'qU_m', Z.dot(W))
+                self.set_param(L, 'qU_W', rng.standard_normal((L.M, L.M)) * 0.01)
+                self.set_param(L, 'qU_a', 1e-3)
+        self._tables()
+        self._elbo_buf = torch.zeros(self.nLayers, **f64)
+        self._winv = {L.index: torch.zeros(L.M, L.M, **f64) for L in self.layers}
+        self._wvec = {L.index: torch.zeros(L.M, L.D, **f64) for L in self.layers}
+        self.opt_array = None
+        self._adam = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # host-side helpers used only at construction (setup, not the hot path)
+    # ------------------------------------------------------------------------------------------------------------
+    def _host_latent(self, i, s, means):
+        T, H = int(self.lat_len[i][s]), self.nDims[i]
+        return means[self.lat_off[i][s]:self.lat_off[i][s] + T * H].reshape(T, H)
+
+    def _host_X_mean(self, i, Ys, Us, means):
+        """Window design matrix of layer i on the host (layers.py:1399-1410) -- initialisation only."""
+        rows = []
+        w = self.wins[i]
+        for s in range(self.nSeq):
+            N = int(self.Ly[s])
+            cols = []
+            if w > 0:
+                own = self._host_latent(i, s, means)[:-1]
+                idx = np.arange(N)[:, None] + np.arange(w)[None, :]
+                cols.append(own[idx].reshape(N, -1))
+            if i == self.nLayers - 1:
+                up, uw = (Us[s], self.U_win) if Us is not None else (None, 0)
+            else:
+                up, uw = self._host_latent(i + 1, s, means), self.wins[i + 1]
+            if up is not None:
+                up = up[up.shape[0] - N - uw + 1:]
+                idx = np.arange(N)[:, None] + np.arange(uw)[None, :]
+                cols.append(up[idx].reshape(N, -1))
+            rows.append(np.hstack(cols))
+        return np.vstack(rows)
+
+    def _host_Y_mean(self, i, means):
+        return np.vstack([self._host_latent(i, s, means)[self.wins[i]:] for s in range(self.nSeq)])
+
+    def _tables(self):
+        dev = self.device
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.int64, device=dev)
+        self.tab = {}
+        for L in self.layers:
+            i = L.index
+            d = {}
+            if i == 0:
+                d['own_off'], d['own_len'] = self.y_off, self.Ly
+            else:
+                d['own_off'], d['own_len'] = self.lat_off[i], self.lat_len[i]
+            if i == self.nLayers - 1:
+                if self.Ucat is not None:
+                    d['up_off'], d['up_len'] = self.u_off, self.u_len
+                else:
+                    d['up_off'], d['up_len'] = np.zeros(self.nSeq, np.int64), np.zeros(self.nSeq, np.int64)
+            else:
+                d['up_off'], d['up_len'] = self.lat_off[i + 1], self.lat_len[i + 1]
+            self.tab[i] = dict(host=d, dev={k: t(v) for k, v in d.items()})
+
+    # ------------------------------------------------------------------------------------------------------------
+    # parameter access
+    # ------------------------------------------------------------------------------------------------------------
+    def layer(self, i):
+        return self.layers[self.nLayers - 1 - i]
+
+    def view(self, L, name, grad=False):
+        a, b, shp = L.slices[name]
+        return (self.grad_array if grad else self.param_array)[a:b].view(*shp)
+
+    def set_param(self, L, name, value):
+        v = torch.as_tensor(np.asarray(value, dtype=np.float64), device=self.device)
+        self.view(L, name).copy_(v.reshape(self.view(L, name).shape))
+
+    def latent(self, i, s, var=False, grad=False):
+        T, H = int(self.lat_len[i][s]), self.nDims[i]
+        base = (self.gvars if var else self.gmeans) if grad else (self.vars if var else self.means)
+        o = int(self.lat_off[i][s])
+        return base[o:o + T * H].view(T, H)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # one objective + gradient evaluation: top-down layer loop (model.py:161-187)
+    # ------------------------------------------------------------------------------------------------------------
+    def _seq_tables(self, L, seqs):
+        tb = self.tab[L.index]
+        if seqs is None:
+            dev = tb['dev']
+            host = tb['host']
+            sl = slice(None)
+        elif isinstance(seqs, slice):
+            sl = seqs
+            dev = {k: v[sl] for k, v in tb['dev'].items()}
+            host = tb['host']
+        else:
+            idx = torch.as_tensor(np.asarray(seqs, dtype=np.int64), device=self.device)
+            dev = {k: v.index_select(0, idx).contiguous() for k, v in tb['dev'].items()}
+            host = tb['host']
+            sl = np.asarray(seqs, dtype=np.int64)
+        own_len = host['own_len'][sl]
+        up_len = host['up_len'][sl]
+        n_seq = len(own_len)
+        N = int(own_len.sum() - n_seq * L.X_win)
+        return dev, n_seq, N, int(own_len.sum()), int(up_len.sum())
+
+    def evaluate(self, seqs=None, qU_ratio=None):
+        """ELBO and all gradients for the sequences ``seqs`` (None = all, slice, or index list).  Returns the device
+        scalar ELBO (also stored in ``grad_array[elbo_slot]``).  Latent gradients are written for the touched sequences
+        only."""
+        h = self.handle
+        n_batch = None
+        self._keep = []
+        for k, L in enumerate(self.layers):
+            dev, n_seq, N, own_rows, up_rows = self._seq_tables(L, seqs)
+            n_batch = n_seq
+            i = L.index
+            lin, lout = LayerIn(), LayerOut()
+            lin.M, lin.D, lin.X_win, lin.X_dim, lin.U_win, lin.U_dim = L.M, L.D, L.X_win, L.X_dim, L.U_win, L.U_dim
+            lin.n_seq, lin.mode, lin.y_uncertain = n_seq, self.mode, 0 if i == 0 else 1
+            lin.N, lin.own_rows, lin.up_rows = N, own_rows, up_rows
+            ratio = float(n_seq) / self.n_total if qU_ratio is None else float(qU_ratio)     # layers.py:328
+            lin.qU_ratio = ratio if self.svi else 1.0
+            lin.up_var_const = 1e-10                                                         # model.py:65
+            self._keep.append(dev)
+            lin.own_off, lin.own_len = dev['own_off'].data_ptr(), dev['own_len'].data_ptr()
+            lin.up_off, lin.up_len = dev['up_off'].data_ptr(), dev['up_len'].data_ptr()
+            if i == 0:
+                lin.own_mean, lin.own_var = self.Ycat.data_ptr(), None
+            else:
+                lin.own_mean, lin.own_var = self.means.data_ptr(), self.vars.data_ptr()
+            if i == self.nLayers - 1:
+                lin.up_mean = self.Ucat.data_ptr() if self.Ucat is not None else None
+                lin.up_var = None
+            else:
+                lin.up_mean, lin.up_var = self.means.data_ptr(), self.vars.data_ptr()
+            for nm in ('Z', 'variance', 'inv_l', 'noise'):
+                setattr(lin, nm, self.view(L, nm).data_ptr())
+            for nm in ('gZ', 'gvariance', 'ginv_l', 'gnoise'):
+                setattr(lout, nm, self.view(L, nm[1:], grad=True).data_ptr())
+            if self.svi:
+                for nm in ('qU_m', 'qU_W', 'qU_a'):
+                    setattr(lin, nm, self.view(L, nm).data_ptr())
+                    setattr(lout, 'g' + nm, self.view(L, nm, grad=True).data_ptr())
+            lout.elbo = self._elbo_buf[k:k + 1].data_ptr()
+            if i > 0:
+                lout.g_own_mean, lout.g_own_var = self.gmeans.data_ptr(), self.gvars.data_ptr()
+            if i < self.nLayers - 1:
+                lout.g_up_mean, lout.g_up_var = self.gmeans.data_ptr(), self.gvars.data_ptr()
+            lout.woodbury_inv, lout.woodbury_vector = self._winv[i].data_ptr(), self._wvec[i].data_ptr()
+            h.layer_step(lin, lout)
+        elbo = self._elbo_buf.sum()
+        self.grad_array[self.elbo_slot] = elbo
+        self._last_n_batch = n_batch
+        return elbo
+
+    def log_likelihood(self, seqs=None):
+        e = float(self.evaluate(seqs).item())
+        self.handle.sync()
+        return e
+
+    # ------------------------------------------------------------------------------------------------------------
+    # paramz-like flat access for tests / L-BFGS (host round trip; not the SVI hot loop)
+    # ------------------------------------------------------------------------------------------------------------
+    def _index_set(self, seqs=None):
+        """Indices of param_array that belong to the globals and to the latents of ``seqs``."""
+        idx = [np.arange(self.n_global)]
+        ss = range(self.nSeq) if seqs is None else seqs
+        for s in ss:
+            a, b = int(self.seq_loc_off[s]), int(self.seq_loc_off[s + 1])
+            idx.append(self.loc0 + np.arange(a, b))
+        for s in ss:
+            a, b = int(self.seq_loc_off[s]), int(self.seq_loc_off[s + 1])
+            idx.append(self.loc0 + self.n_local + np.arange(a, b))
+        return torch.as_tensor(np.concatenate(idx), device=self.device)
+
+    def get_optimizer_array(self, seqs=None):
+        idx = self._index_set(seqs)
+        p = self.param_array[idx]
+        pos = self.positive[idx].bool()
+        return torch.where(pos, _softplus_inv(p), p).cpu().numpy()
+
+    def set_optimizer_array(self, x, seqs=None):
+        idx = self._index_set(seqs)
+        x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=self.device)
+        pos = self.positive[idx].bool()
+        self.param_array[idx] = torch.where(pos, _softplus(x), x)
+
+    def objective_and_grad(self, x, seqs=None):
+        """(-ELBO, -dELBO/dx) in optimiser space on the host (paramz' objective_function / _grads)."""
+        self.set_optimizer_array(x, seqs)
+        e = self.evaluate(seqs)
+        idx = self._index_set(seqs)
+        g = self.grad_array[idx]
+        p = self.param_array[idx]
+        pos = self.positive[idx].bool()
+        g = torch.where(pos, g * (-torch.expm1(-p)), g)
+        self.handle.sync()
+        return -float(e.item()), -g.cpu().numpy()
+
+    def optimize(self, optimizer='bfgs', max_iters=100, messages=0):
+        """``m.optimize('bfgs', max_iters=...)`` of the reference (paramz -> scipy L-BFGS-B), full batch."""
+        from scipy.optimize import fmin_l_bfgs_b
+        x0 = self.get_optimizer_array()
+        x, f, d = fmin_l_bfgs_b(self.objective_and_grad, x0, maxfun=max_iters, maxiter=max_iters, iprint=1 if messages else -1)
+        self.set_optimizer_array(x)
+        return f, d
+
+    # ------------------------------------------------------------------------------------------------------------
+    # SVI loop: Adam on device (global bucket + the touched sequences' local parameters)
+    # ------------------------------------------------------------------------------------------------------------
+    def _init_adam(self):
+        self.opt_array = torch.where(self.positive.bool(), _softplus_inv(self.param_array), self.param_array).contiguous()
+        self._adam = dict(m=torch.zeros_like(self.param_array), v=torch.zeros_like(self.param_array),
+                          t_glob=0, t_loc=np.zeros(self.nSeq, dtype=np.int64))
+
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None):
+        """One SVI step on the sequences ``seqs`` (slice of contiguous indices or index list): ELBO + gradients,
+        optional all-reduce of the global bucket (data-parallel), one Adam update of the global parameters and of the
+        touched sequences' latent parameters.  Returns the device ELBO scalar (pre-update)."""
+        if self._adam is None:
+            self._init_adam()
+        ad, h = self._adam, self.handle
+        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        if allreduce is not None:
+            allreduce(self.grad_array[:self.n_global + 1])
+            elbo = self.grad_array[self.elbo_slot]
+        ad['t_glob'] += 1
+        G = self.n_global
+        h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
+                    self.positive[:G], lr, ad['t_glob'])
+        if isinstance(seqs, slice):
+            ranges = [(seqs.start or 0, seqs.stop if seqs.stop is not None else self.nSeq)]
+        elif seqs is None:
+            ranges = [(0, self.nSeq)]
+        else:
+            ranges = [(int(s), int(s) + 1) for s in seqs]
+        for (s0, s1) in ranges:
+            ad['t_loc'][s0:s1] += 1
+            t = int(ad['t_loc'][s0])
+            a, b = int(self.seq_loc_off[s0]), int(self.seq_loc_off[s1])
+            for base in (self.loc0, self.loc0 + self.n_local):
+                sl = slice(base + a, base + b)
+                h.adam_step(self.opt_array[sl], self.param_array[sl], self.grad_array[sl], ad['m'][sl], ad['v'][sl],
+                            self.positive[sl], lr, t)
+        return elbo
+
+    # ------------------------------------------------------------------------------------------------------------
+    # parity helpers
+    # ------------------------------------------------------------------------------------------------------------
+    def load_from_oracle(self, om):
+        """Copy every parameter of an oracle.model.DeepAutoreg with the same structure (tests / smoke only)."""
+        for L in self.layers:
+            p = om.P[L.index]
+            self.set_param(L, 'Z', p.Z)
+            self.set_param(L, 'variance', p.variance)
+            self.set_param(L, 'inv_l', p.inv_l)
+            self.set_param(L, 'noise', p.noise)
+            if self.svi:
+                self.set_param(L, 'qU_m', p.qU_m)
+                self.set_param(L, 'qU_W', p.qU_W)
+                self.set_param(L, 'qU_a', p.qU_a)
+        for i in range(1, self.nLayers):
+            for s in range(self.nSeq):
+                self.latent(i, s).copy_(torch.as_tensor(om.Xmean[i][s], device=self.device))
+                self.latent(i, s, var=True).copy_(torch.as_tensor(om.Xvar[i][s], device=self.device))
+        self._adam = None
+
+    def grads_as_oracle_dict(self, seqs=None):
+        G = {}
+        for L in self.layers:
+            for nm in L.slices:
+                g = self.view(L, nm, grad=True).cpu().numpy()
+                G[(L.index, nm)] = g if g.size > 1 else float(g.reshape(-1)[0])
+        ss = range(self.nSeq) if seqs is None else seqs
+        for i in range(1, self.nLayers):
+            for s in ss:
+                G[(i, 'Xmean', s)] = self.latent(i, s, grad=True).cpu().numpy()
+                G[(i, 'Xvar', s)] = self.latent(i, s, var=True, grad=True).cpu().numpy()
+        return G
+
+
+DeepAutoreg_new = DeepAutoreg

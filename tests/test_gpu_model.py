@@ -1,0 +1,120 @@
+"""GPU parity of the fused layer step / whole-model ELBO and gradients against the oracle model, plus the reference's
+own invariants (checkgrad, additivity and permutation over minibatches: testing/minibatch_tests.py:98-100,281-296)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_data(n_seq, T, u_dim=2, y_dim=3, seed=0, ragged=False):
+    rng = np.random.default_rng(seed)
+    U, Y = [], []
+    for s in range(n_seq):
+        t = T + (3 * s if ragged else 0)
+        U.append(rng.standard_normal((t, u_dim)))
+        Y.append(np.tanh(np.cumsum(rng.standard_normal((t, y_dim)), 0) * 0.3) + 0.1 * rng.standard_normal((t, y_dim)))
+    return U, Y
+
+
+def build_pair(n_seq=3, T=14, wins=(0, 3, 3), nDims=(3, 2, 3), M=4, U_win=2, seed=0, ragged=False, n_total=None,
+               u_dim=2, y_dim=3):
+    from oracle import model as om
+    from rgp_amd.model import DeepAutoreg
+    U, Y = make_data(n_seq, T, u_dim, y_dim, seed, ragged)
+    o = om.DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
+                       inference_method='svi', n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=False)
+    rng = np.random.default_rng(seed + 2)
+    for i in o.order:
+        p = o.P[i]
+        p.inv_l[:] = 0.3 + rng.random(p.inv_l.shape)
+        p.variance = 0.7 + rng.random()
+        p.noise = 0.1 + 0.3 * rng.random()
+        p.qU_W[:] = rng.standard_normal(p.qU_W.shape) * 0.2
+        p.qU_a = 0.3
+    for i in range(1, len(wins)):
+        for s in range(n_seq):
+            o.Xvar[i][s][:] = 0.02 + 0.1 * rng.random(o.Xvar[i][s].shape)
+            o.Xmean[i][s][:] += 0.1 * rng.standard_normal(o.Xmean[i][s].shape)
+    g = DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
+                    inference_method='svi', mb_inf_tot_data_size=n_total, seed=seed)
+    g.load_from_oracle(o)
+    return o, g
+
+
+def compare(o, g, seqs=None, rtol=1e-9):
+    import torch
+    eo, Go = o.elbo_and_grads(seqs)
+    eg = float(g.evaluate(seqs).item())
+    g.handle.sync()
+    assert abs(eg - eo) <= 1e-11 * abs(eo), (eg, eo)
+    Gg = g.grads_as_oracle_dict(seqs if seqs is not None else None)
+    for k, v in Go.items():
+        a, b = np.asarray(Gg[k], dtype=float), np.asarray(v, dtype=float)
+        scale = max(np.abs(b).max(), 1e-12)
+        assert np.abs(a.reshape(b.shape) - b).max() <= rtol * scale, (k, np.abs(a.reshape(b.shape) - b).max(), scale)
+    return eo
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(),                                                        # the reference tests' 2-hidden-layer shape
+    dict(wins=(0, 3), nDims=(3, 2), n_seq=2),                      # 1 hidden layer
+    dict(ragged=True, n_seq=4),                                    # sequences of different length
+    dict(wins=(0, 5, 4, 3), nDims=(2, 1, 2, 1), n_seq=2, T=16, M=6, y_dim=2),   # 3 hidden layers, mixed windows
+    dict(wins=(0, 20, 20), nDims=(16, 1, 1), n_seq=2, T=64, M=100, U_win=20, u_dim=1, y_dim=16),   # config-4 geometry
+])
+def test_elbo_and_gradients_match_oracle(cfg):
+    o, g = build_pair(**cfg)
+    compare(o, g)
+
+
+def test_minibatch_subset_permutation_additivity():
+    o, g = build_pair(n_seq=6, T=12, n_total=6)
+    e_all = compare(o, g)
+    Gall = {k: np.array(v) for k, v in g.grads_as_oracle_dict().items()}
+    compare(o, g, [4, 2, 0, 5, 1, 3])                               # permutation
+    Gperm = g.grads_as_oracle_dict()
+    for k in Gall:
+        if len(k) == 2:
+            assert np.allclose(Gperm[k], Gall[k], rtol=1e-11, atol=0) or np.abs(np.asarray(Gperm[k]) - Gall[k]).max() < 1e-11 * np.abs(Gall[k]).max()
+    e1 = float(g.evaluate(slice(0, 3)).item())                      # contiguous slices (StdMemoryDataStreamer)
+    G1 = {k: np.array(v) for k, v in g.grads_as_oracle_dict([0, 1, 2]).items()}
+    e2 = float(g.evaluate(slice(3, 6)).item())
+    G2 = {k: np.array(v) for k, v in g.grads_as_oracle_dict([3, 4, 5]).items()}
+    assert np.isclose(e1 + e2, e_all, rtol=1e-13, atol=0)           # testing/minibatch_tests.py:288-296
+    for k in Gall:
+        if len(k) == 2:
+            s = np.asarray(G1[k]) + np.asarray(G2[k])
+            assert np.abs(s - Gall[k]).max() <= 1e-10 * max(np.abs(Gall[k]).max(), 1e-12), k
+    compare(o, g, [1, 4])                                           # arbitrary subset with qU_ratio = 2/6
+
+
+def test_checkgrad_device():
+    o, g = build_pair(n_seq=2, T=10)
+    x0 = g.get_optimizer_array()
+    f0, g0 = g.objective_and_grad(x0)
+    rng = np.random.default_rng(3)
+    idx = rng.choice(x0.size, size=40, replace=False)
+    eps = 1e-6
+    for j in idx:
+        xp = x0.copy(); xp[j] += eps
+        xm = x0.copy(); xm[j] -= eps
+        num = (g.objective_and_grad(xp)[0] - g.objective_and_grad(xm)[0]) / (2 * eps)
+        assert abs(num - g0[j]) <= 1e-5 * max(1.0, abs(num)), (j, num, g0[j])
+
+
+def test_svi_steps_track_oracle_adam():
+    """A few Adam steps on the device follow the same trajectory as NumPy Adam on the oracle's gradients."""
+    o, g = build_pair(n_seq=4, T=12, n_total=4)
+    lr = 1e-2
+    x = o.get_optimizer_array(); m = np.zeros_like(x); v = np.zeros_like(x)
+    for step in (1, 2, 3):
+        f, gr = o.objective_and_grad(x)
+        gr = -gr
+        m = 0.9 * m + 0.1 * gr; v = 0.999 * v + 0.001 * gr * gr
+        x = x + lr * (m / (1 - 0.9 ** step)) / (np.sqrt(v / (1 - 0.999 ** step)) + 1e-8)
+        eg = float(g.svi_step(slice(0, 4), lr=lr).item())
+        assert abs(eg + f) <= 1e-9 * abs(f), (step, eg, f)
+    o.set_optimizer_array(x)
+    eo = o.elbo_and_grads()[0]
+    eg = g.log_likelihood()
+    assert abs(eg - eo) <= 1e-8 * abs(eo)
