@@ -95,6 +95,12 @@ rgp_status rgp_sync_status(rgp_handle h, int* pivot);
 /* Upper bound of the workspace (bytes) a layer step of this geometry needs; the workspace grows on demand. */
 int64_t    rgp_workspace_bytes(int64_t N, int M, int Q, int D);
 
+/* Optional in-library timing of the dominant kernel (the fused psi2 pass): when on, rgp_layer_step brackets that
+ * launch with HIP events on the handle's stream; rgp_get_profile synchronises those events and returns the summed
+ * duration [ms], the number of launches and the summed algorithmic work sum(N*M*M*Q) since the last reset. */
+rgp_status rgp_set_profiling(rgp_handle h, int on);
+rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches, double* psi2_nmmq, int reset);
+
 /* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,
  *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);

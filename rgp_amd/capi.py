@@ -62,6 +62,14 @@ class Handle(object):
     def scalar(self, v):
         return torch.tensor([float(v)], dtype=torch.float64, device=self.device)
 
+    def set_profiling(self, on=True):
+        self._check(self.lib.rgp_set_profiling(self.h, 1 if on else 0))
+
+    def get_profile(self, reset=True):
+        ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._check(self.lib.rgp_get_profile(self.h, C.byref(ms), C.byref(n), C.byref(w), 1 if reset else 0))
+        return ms.value, n.value, w.value
+
     # ---- unit pieces ---------------------------------------------------------------------------------------------
     def kuu(self, Z, variance, inv_l, jitter=1e-6):
         _chk64(Z, variance, inv_l)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/rgp_hip.h"
 
@@ -37,6 +38,11 @@ struct rgp_ctx {
   size_t ws_bytes = 0;
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
   int num_cu = 256;
+  // optional profiling of the psi2 launch (rgp_set_profiling)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_nmmq = 0.0;
 };
 
 struct WsAlloc {           // bump allocator over the handle's workspace

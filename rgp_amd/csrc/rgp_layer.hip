@@ -68,6 +68,44 @@ extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
   return RGP_OK;
 }
 
+extern "C" rgp_status rgp_set_profiling(rgp_handle h, int on) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  h->profiling = on != 0;
+  return RGP_OK;
+}
+
+extern "C" rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches, double* psi2_nmmq, int reset) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  double tot = 0.0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0.f;
+    RGP_HIP_CHECK(h, hipEventSynchronize(h->prof_events[i].second));
+    RGP_HIP_CHECK(h, hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+    tot += ms;
+  }
+  if (psi2_ms) *psi2_ms = tot;
+  if (psi2_launches) *psi2_launches = (int64_t)h->prof_used;
+  if (psi2_nmmq) *psi2_nmmq = h->prof_nmmq;
+  if (reset) { h->prof_used = 0; h->prof_nmmq = 0.0; }
+  return RGP_OK;
+}
+
+static void prof_begin(rgp_handle h, double nmmq) {
+  if (!h->profiling) return;
+  if (h->prof_used == h->prof_events.size()) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    h->prof_events.push_back({a, b});
+  }
+  h->prof_nmmq += nmmq;
+  (void)hipEventRecord(h->prof_events[h->prof_used].first, h->stream);
+}
+static void prof_end(rgp_handle h) {
+  if (!h->profiling) return;
+  (void)hipEventRecord(h->prof_events[h->prof_used].second, h->stream);
+  h->prof_used++;
+}
+
 // ==================================================================================================================
 // small kernels of the layer step
 // ==================================================================================================================
@@ -613,7 +651,10 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     Psi2Out o{};
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
-    if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
+    prof_begin(h, (double)N * M * M * Q);
+    st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2);
+    prof_end(h);
+    if (st) return st;
     const int tri = M * (M + 1) / 2;
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
