@@ -413,7 +413,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.nblk1 = NBLK1;
   L.nblk2 = (int)psi2_num_blocks(h, N);
   L.zt.M = M; L.zt.Q = Q; L.zt.QP = QP;
-  L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP);
+  L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP); L.zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.zt.zd = ws.take<double>((size_t)M * M); L.zt.Kuu = ws.take<double>((size_t)M * M);
   L.rt.N = N; L.rt.QP = QP;
   L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq);
@@ -424,7 +424,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.p2_part = ws.take<double>((size_t)L.nblk2 * tri); L.p2_tri = ws.take<double>(tri);
   L.psi2 = ws.take<double>((size_t)M * M); L.dLs = ws.take<double>((size_t)M * M);
   L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
-  L.dz2_part = ws.take<double>((size_t)L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
+  L.dz2_part = ws.take<double>((size_t)2 * L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.dlam1_part = ws.take<double>((size_t)L.nblk1 * QP); L.dlam1 = ws.take<double>(QP);
   L.dlam2_part = ws.take<double>((size_t)L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
   L.lsum1_part = ws.take<double>(L.nblk1); L.lsum1 = ws.take<double>(1);
@@ -534,7 +534,7 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
     const int tri = M * (M + 1) / 2;
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
-    launch_reduce(s, L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
     launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
     launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
@@ -658,7 +658,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     const int tri = M * (M + 1) / 2;
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
-    launch_reduce(s, L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
     launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
     launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }

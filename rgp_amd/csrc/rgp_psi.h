@@ -12,6 +12,7 @@ struct ZTerms {
   double* c;      // [QP]  column mean of Z (shift; the bound is translation invariant)
   double* lam;    // [QP]  inv_l padded with zeros
   double* Zc;     // [M x QP]  Z - c, zero padded
+  double* ZcT;    // [QP x 128] transposed copy (per-lane rows read coalesced)
   double* zd;     // [M x M]   -1/4 sum_q lam_q (z_mq - z_m'q)^2
   double* Kuu;    // [M x M]   variance*exp(-1/2 r^2) + jitter*I
 };

@@ -21,7 +21,7 @@
 __global__ void __launch_bounds__(256) prep_z_kernel(int M, int Q, int QP, const double* __restrict__ Z,
                                                       const double* __restrict__ variance,
                                                       const double* __restrict__ inv_l, double jitter, double* c,
-                                                      double* lam, double* Zc, double* zd, double* Kuu) {
+                                                      double* lam, double* Zc, double* ZcT, double* zd, double* Kuu) {
   const int t = threadIdx.x;
   for (int q = t; q < QP; q += blockDim.x) {
     double s = 0.0;
@@ -36,6 +36,10 @@ __global__ void __launch_bounds__(256) prep_z_kernel(int M, int Q, int QP, const
   for (int i = t; i < M * QP; i += blockDim.x) {
     const int m = i / QP, q = i % QP;
     Zc[i] = q < Q ? Z[(size_t)m * Q + q] - c[q] : 0.0;
+  }
+  for (int i = t; i < QP * RGP_PSI2_TEAM; i += blockDim.x) {     // transposed, row-padded copy: coalesced per-lane rows
+    const int q = i / RGP_PSI2_TEAM, m = i % RGP_PSI2_TEAM;
+    ZcT[i] = (q < Q && m < M) ? Z[(size_t)m * Q + q] - c[q] : 0.0;
   }
   __syncthreads();
   const double var = variance[0];
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(256) prep_z_kernel(int M, int Q, int QP, const
 void launch_prep_z(hipStream_t s, int M, int Q, int QP, const double* Z, const double* variance, const double* inv_l,
                    double jitter, const ZTerms& zt) {
   hipLaunchKernelGGL(prep_z_kernel, dim3(1), dim3(256), 0, s, M, Q, QP, Z, variance, inv_l, jitter, zt.c, zt.lam, zt.Zc,
-                     zt.zd, zt.Kuu);
+                     zt.ZcT, zt.zd, zt.Kuu);
 }
 
 __global__ void row_offsets_kernel(int n_seq, int X_win, const int64_t* __restrict__ own_len, int64_t* row_off) {
@@ -361,186 +365,205 @@ void launch_psi1_dz(hipStream_t s, int64_t N, int M, const ZTerms& zt, const Row
 // ------------------------------------------------------------------------------------------------------------------
 struct Psi2Args {
   int64_t N; int M, Q;
-  const double *Zc, *zd, *lam, *dLs;
+  const double *Zc, *ZcT, *zd, *lam, *dLs;
   const double *Xmu, *d2, *g0;
   Psi2Out o;
 };
 
-#define RED_QC 8                 // q columns per reduction chunk (2*RED_QC values x 128 threads)
-#define RED_RS 136               // padded row stride of the reduction buffer (conflict-free)
+#define RED_QC 4                 // q columns per reduction chunk: each WAVE transposes 2*RED_QC values x 64 lanes in its own
+#define RED_RS 72                // LDS region (no workgroup barrier); row stride 72 doubles = 16 mod 64 dwords keeps the four
+                                 // value rows a 32-lane group reads in disjoint banks
+#define RED_WAVE (2 * RED_QC * RED_RS)
+#define PSI2_THREADS 256         // 2 halves x 128 inducing rows: half h sweeps m' in [h*ceil(M/2), ...)
+
+// One (row n, inducing pair m,m') step.  zs = z[m',:] is wave-uniform (SGPR operands).
+//   E = base + hb[m'] - 1/2 sum_q dzl[q] zs[q],  dzl = z_m (d2_n - lam)  (the Zdist factor is folded into the Gram:
+//   -1/4 sum lam (z_m - z_m')^2 = -1/4 l_m - 1/4 l_m' + 1/2 sum lam z_m z_m', with l_m carried inside base / hb)
+template <int QP, bool FWD, bool BWD>
+static __device__ __forceinline__ void psi2_pair(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
+                                                 double& v, const double base, const double hbm, const double dlv,
+                                                 double* __restrict__ p2slot) {
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; q += 4) {
+    c0 += dzl[q] * zs[q];
+    c1 += dzl[q + 1] * zs[q + 1];
+    c2 += dzl[q + 2] * zs[q + 2];
+    c3 += dzl[q + 3] * zs[q + 3];
+  }
+  const double E = (base + hbm) - 0.5 * ((c0 + c1) + (c2 + c3));
+  const double p = exp(E);
+  if (FWD) atomicAdd(p2slot, p);          // ds_add_f64, no return: the slot has exactly one owner thread -> deterministic
+  if (BWD) {
+    const double w = p * dlv;
+    v += w;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] += w * zs[q];
+  }
+}
 
 // Every pointer is a separate noalias kernel argument: that is what lets the compiler prove the wave-uniform loads
 // of z[m',:], d2[n,:] and mu[n,:] are not clobbered by the kernel's own stores and turn them into scalar loads.
-template <int QP, int NB, bool FWD, bool BWD>
-__global__ void __launch_bounds__(RGP_PSI2_TEAM, 1)
-psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __restrict__ Zc, const double* __restrict__ zd_g,
-                 const double* __restrict__ lam_g, const double* __restrict__ dLs_g, const double* __restrict__ Xmu_g,
-                 const double* __restrict__ d2_g, const double* __restrict__ g0_g, double* __restrict__ p2_part,
-                 double* __restrict__ dz_part, double* __restrict__ dlam_part, double* __restrict__ wsum_part,
-                 double* __restrict__ gmu_g, double* __restrict__ gS_g, const int accumulate) {
+// Occupancy: 2 workgroups (8 waves) per CU = 2 waves per SIMD; measured v_fma_f64 throughput is 31 TF at 1 wave/SIMD
+// and 63.5 TF at 2 (profiles/r1_f64_peak.txt), so the register budget is capped at 256 by __launch_bounds__.
+template <int QP, bool FWD, bool BWD>
+__global__ void __launch_bounds__(PSI2_THREADS, 2)
+psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __restrict__ Zc, const double* __restrict__ ZcT,
+                 const double* __restrict__ lam_g,
+                 const double* __restrict__ dLs_g, const double* __restrict__ Xmu_g, const double* __restrict__ d2_g,
+                 const double* __restrict__ g0_g, double* __restrict__ p2_part, double* __restrict__ dz_part,
+                 double* __restrict__ dlam_part, double* __restrict__ wsum_part, double* __restrict__ gmu_g,
+                 double* __restrict__ gS_g, const int accumulate) {
   extern __shared__ double lds[];
-  struct { int64_t N; int M, Q; const double *zd, *lam, *dLs, *Xmu, *d2, *g0;
-           struct { double *p2_part, *dz_part, *dlam_part, *wsum_part, *gmu, *gS; int accumulate; } o; } a;
-  a.N = N; a.M = M; a.Q = Q; a.zd = zd_g; a.lam = lam_g; a.dLs = dLs_g; a.Xmu = Xmu_g; a.d2 = d2_g; a.g0 = g0_g;
-  a.o.p2_part = p2_part; a.o.dz_part = dz_part; a.o.dlam_part = dlam_part; a.o.wsum_part = wsum_part;
-  a.o.gmu = gmu_g; a.o.gS = gS_g; a.o.accumulate = accumulate;
   const int tri = M * (M + 1) / 2;
-  double* p2acc = lds;                                   // [tri]           (FWD)
-  double* hbuf = lds + (FWD ? tri : 0);                  // [NB x 128]
-  double* red = hbuf + NB * RGP_PSI2_TEAM;               // [2*RED_QC x RED_RS]   (BWD)
-  double* res = red + (BWD ? 2 * RED_QC * RED_RS : 0);   // [2*QP]                (BWD)
-  double* scratch = res + (BWD ? 2 * QP : 0);            // [16]
+  double* p2acc = lds;                                   // [tri + 128] (+128 dummy slots)   (FWD)
+  double* hbuf = lds + (FWD ? tri + RGP_PSI2_TEAM : 0);  // [128]
+  double* red = hbuf + RGP_PSI2_TEAM;                    // [4 waves x RED_WAVE]          (BWD)
+  double* res = red + (BWD ? 4 * RED_WAVE : 0);          // [4 waves x (2*QP + 8)]        (BWD)
 
   const int t = threadIdx.x;
-  const bool act = t < M;
-  const int tm = act ? t : M - 1;
-  const double* __restrict__ zrow = Zc + (size_t)tm * QP;
+  const int tr = t & (RGP_PSI2_TEAM - 1);                // inducing row owned by this thread
+  const int half = __builtin_amdgcn_readfirstlane(t >> 7);   // which half of the m' sweep (wave-uniform: keeps z[m'] in SGPRs)
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  const int Mh = (M + 1) >> 1;
+  const int mp0 = half ? Mh : 0, mp1 = half ? M : Mh;
+  const double* __restrict__ zrowp = Zc + (size_t)tm * QP;   // (a transposed, coalesced copy ZcT was measured slower: 17.0 vs 12.7 ms)
+#define zrow(q) zrowp[q]
 
   if (FWD) {
-    for (int i = t; i < tri; i += RGP_PSI2_TEAM) p2acc[i] = 0.0;
+    for (int i = t; i < tri + RGP_PSI2_TEAM; i += PSI2_THREADS) p2acc[i] = 0.0;
   }
-  double* dzp = BWD ? a.o.dz_part + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM : nullptr;   // layout [q][t]
-  if (BWD) {
+  // dZ partial of this (block, half): layout [q][row]
+  double* dzp = BWD ? dz_part + ((size_t)blockIdx.x * 2 + half) * QP * RGP_PSI2_TEAM : nullptr;
+  double ellq = 0.0;                                     // 1/4 sum_q lam_q z_mq^2
 #pragma unroll
-    for (int q = 0; q < QP; ++q) dzp[q * RGP_PSI2_TEAM + t] = 0.0;
+  for (int q = 0; q < QP; ++q) {
+    if (BWD) dzp[q * RGP_PSI2_TEAM + tr] = 0.0;
+    ellq += 0.25 * lam_g[q] * zrow(q) * zrow(q);
   }
   double dlam_acc = 0.0, wsum_acc = 0.0;
   __syncthreads();
 
-  const int64_t per = ((a.N + gridDim.x - 1) / gridDim.x + NB - 1) / NB * NB;
+  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per;
-  const int64_t r1 = (r0 + per < a.N) ? r0 + per : a.N;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  const double* __restrict__ dlrow = dLs_g + tm;          // dLs[m'][m]: coalesced over the lanes' rows
 
-  for (int64_t row = r0; row < r1; row += NB) {
-    double dz[NB][QP];
-    double hb[NB], g0b[NB];
-    int64_t nrow[NB];
+  for (int64_t n = r0; n < r1; ++n) {
+    asm volatile("" ::: "memory");                          // keep the per-row reloads of z[m,:] out of the registers
+    const double* __restrict__ dn = d2_g + n * QP;          // wave-uniform -> scalar loads
+    const double* __restrict__ mun = Xmu_g + n * QP;
+    double dzl[QP];
+    double h0 = 0.0, h1 = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const bool valid = row + b < r1;
-      const int64_t n = valid ? row + b : r1 - 1;
-      nrow[b] = n;
-      const double* __restrict__ dn = a.d2 + n * QP;       // wave-uniform -> scalar loads
-      const double* __restrict__ mun = a.Xmu + n * QP;
-      double h0 = 0.0, h1 = 0.0;
-#pragma unroll
-      for (int q = 0; q < QP; q += 2) {
-        const double z0 = zrow[q], z1 = zrow[q + 1];
-        dz[b][q] = z0 * dn[q];
-        dz[b][q + 1] = z1 * dn[q + 1];
-        h0 += dz[b][q] * (mun[q] - 0.25 * z0);
-        h1 += dz[b][q + 1] * (mun[q + 1] - 0.25 * z1);
-      }
-      const double h = h0 + h1;
-      hbuf[b * RGP_PSI2_TEAM + t] = h;
-      hb[b] = (act && valid) ? h : -INFINITY;              // exp(-inf) = 0: padded lanes / rows contribute nothing
-      g0b[b] = a.g0[n];
+    for (int q = 0; q < QP; q += 2) {
+      const double z0 = zrow(q), z1 = zrow(q + 1);
+      dzl[q] = z0 * (dn[q] - lam_g[q]);
+      dzl[q + 1] = z1 * (dn[q + 1] - lam_g[q + 1]);
+      h0 += z0 * dn[q] * (mun[q] - 0.25 * z0);
+      h1 += z1 * dn[q + 1] * (mun[q + 1] - 0.25 * z1);
     }
+    const double h = (h0 + h1) - ellq;
+    if (half == 0) hbuf[tr] = h;
+    const double base = act ? (g0_g[n] + h) : -INFINITY;    // exp(-inf) = 0: padded lanes contribute nothing
     __syncthreads();
 
-    double y[NB][QP];
-    double v[NB];
+    double y[QP];
+    double v = 0.0;
     if (BWD) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        v[b] = 0.0;
-#pragma unroll
-        for (int q = 0; q < QP; ++q) y[b][q] = 0.0;
-      }
+      for (int q = 0; q < QP; ++q) y[q] = 0.0;
     }
-    double zd_next = a.zd[tm];
-    double dl_next = BWD ? a.dLs[tm] : 0.0;
-    for (int mp = 0; mp < M; ++mp) {
-      const double* __restrict__ zs = Zc + (size_t)mp * QP;    // wave-uniform row of z
-      const double zdv = zd_next, dlv = dl_next;
-      const int mn = (mp + 1 < M) ? mp + 1 : mp;
-      zd_next = a.zd[(size_t)mn * M + tm];
-      if (BWD) dl_next = a.dLs[(size_t)mn * M + tm];
-      double psum = 0.0;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-#pragma unroll
-        for (int q = 0; q < QP; q += 4) {
-          c0 += dz[b][q] * zs[q];
-          c1 += dz[b][q + 1] * zs[q + 1];
-          c2 += dz[b][q + 2] * zs[q + 2];
-          c3 += dz[b][q + 3] * zs[q + 3];
-        }
-        const double E = (zdv + g0b[b] + hb[b]) + hbuf[b * RGP_PSI2_TEAM + mp] - 0.5 * ((c0 + c1) + (c2 + c3));
-        const double p = exp(E);
-        psum += p;
-        if (BWD) {
-          const double w = p * dlv;
-          v[b] += w;
-#pragma unroll
-          for (int q = 0; q < QP; ++q) y[b][q] += w * zs[q];
-        }
+    // dLs[m', m] stream: two loads in flight (prefetch distance 2), consumed in registers without rotation copies
+    const int last = mp1 - 1;
+    double dlA = BWD ? dlrow[(size_t)mp0 * M] : 0.0;
+    double dlB = BWD ? dlrow[(size_t)((mp0 + 1 < mp1) ? mp0 + 1 : last) * M] : 0.0;
+    for (int mp = mp0; mp < mp1; mp += 2) {
+      const int mpa = mp, mpb = (mp + 1 < mp1) ? mp + 1 : last;
+      const double dla = dlA, dlb = dlB;
+      if (BWD) {
+        dlA = dlrow[(size_t)((mp + 2 < mp1) ? mp + 2 : last) * M];
+        dlB = dlrow[(size_t)((mp + 3 < mp1) ? mp + 3 : last) * M];
       }
-      if (FWD) {
-        if (act && mp >= t) p2acc[mp * (mp + 1) / 2 + t] += psum;
+      {
+        const bool own = act && mpa >= tr;
+        psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpa * QP, dzl, y, v, base, hbuf[mpa], dla,
+                                p2acc + (own ? mpa * (mpa + 1) / 2 + tr : tri + tr));
+      }
+      if (mp + 1 < mp1) {
+        const bool own = act && mpb >= tr;
+        psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpb * QP, dzl, y, v, base, hbuf[mpb], dlb,
+                                p2acc + (own ? mpb * (mpb + 1) / 2 + tr : tri + tr));
       }
     }
 
     if (BWD) {
+      asm volatile("" ::: "memory");
+      // dZ partial:  d (v (2 mu - z) - y)      (linear in v and y, so each half adds its own share)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const bool valid = row + b < r1;
-        const int64_t n = nrow[b];
-        const double* __restrict__ dn = a.d2 + n * QP;
-        const double* __restrict__ mun = a.Xmu + n * QP;
-        const double vb = valid ? v[b] : 0.0;
-        // dZ partial:  v d (2 mu - z) - d y
-#pragma unroll
-        for (int q = 0; q < QP; ++q) {
-          const double z = zrow[q];
-          dzp[q * RGP_PSI2_TEAM + t] += dn[q] * (vb * (2.0 * mun[q] - z) - (valid ? y[b][q] : 0.0));
-        }
-        const double w = block_sum(vb, scratch);
-        // a1[q] = sum_m v z ; a23[q] = 1/2 sum_m z (v z + y)
+      for (int q = 0; q < QP; ++q) {
+        const double z = zrow(q);
+        dzp[q * RGP_PSI2_TEAM + tr] += dn[q] * (v * (2.0 * mun[q] - z) - y[q]);
+      }
+      // a1[q] = sum_m v z ; a23[q] = 1/2 sum_m z (v z + y) ; w = sum_m v   (sums over both halves and all rows).
+      // Each wave reduces its 64 lanes through its own LDS region (in-order LDS, no workgroup barrier), then one barrier
+      // and a 4-term sum per value.
+      {
+        const int wave = t >> 6, lane = t & 63;
+        double* wred = red + wave * RED_WAVE;
+        double* wres = res + wave * (2 * QP + 8);
+        const double ws = wave_sum(v);
+        if (lane == 0) wres[2 * QP] = ws;
         for (int q0 = 0; q0 < QP; q0 += RED_QC) {
 #pragma unroll
           for (int j = 0; j < RED_QC; ++j) {
-            const double z = zrow[q0 + j];
-            red[j * RED_RS + t] = vb * z;
-            red[(RED_QC + j) * RED_RS + t] = 0.5 * z * (vb * z + (valid ? y[b][q0 + j] : 0.0));
+            const double z = zrow(q0 + j);
+            wred[j * RED_RS + lane] = v * z;
+            wred[(RED_QC + j) * RED_RS + lane] = 0.5 * z * (v * z + y[q0 + j]);
           }
-          __syncthreads();
-          {
-            const int jv = t >> 3, part = t & 7;           // 16 values x 8 partial sums
-            double s = 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int jv = lane >> 3, part = lane & 7;       // 8 values x 8 partial sums of 8 entries
+          double sacc = 0.0;
 #pragma unroll
-            for (int k = 0; k < RGP_PSI2_TEAM / 8; ++k) s += red[jv * RED_RS + part + 8 * k];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            if (part == 0) res[(jv < RED_QC ? 0 : QP) + q0 + (jv % RED_QC)] = s;
-          }
-          __syncthreads();
+          for (int k = 0; k < 8; ++k) sacc += wred[jv * RED_RS + part + 8 * k];
+          sacc += __shfl_xor(sacc, 1);
+          sacc += __shfl_xor(sacc, 2);
+          sacc += __shfl_xor(sacc, 4);
+          if (part == 0) wres[(jv < RED_QC ? 0 : QP) + q0 + (jv % RED_QC)] = sacc;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (t < a.Q && valid) {
-          const int q = t;
-          const double mu = mun[q], dq = dn[q];
-          const double a1 = res[q], a23 = res[QP + q];
-          const double dmu = 2.0 * dq * (a1 - mu * w);
-          const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
-          const double dS = -2.0 * dq * dq * dd;
-          if (a.o.accumulate) {
-            a.o.gmu[n * QP + q] += dmu;
-            a.o.gS[n * QP + q] += dS;
-          } else {
-            a.o.gmu[n * QP + q] = dmu;
-            a.o.gS[n * QP + q] = dS;
-          }
-          const double il = 1.0 / a.lam[q];
-          dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
-        } else if (t >= a.Q && t < QP && valid && !a.o.accumulate) {
-          a.o.gmu[n * QP + t] = 0.0;
-          a.o.gS[n * QP + t] = 0.0;
-        }
-        if (t == 0) wsum_acc += w;
-        __syncthreads();
       }
+      __syncthreads();
+      const int RW = 2 * QP + 8;
+      const double w = (res[2 * QP] + res[RW + 2 * QP]) + (res[2 * RW + 2 * QP] + res[3 * RW + 2 * QP]);
+      if (t < Q) {
+        const int q = t;
+        const double mu = mun[q], dq = dn[q];
+        const double a1 = (res[q] + res[RW + q]) + (res[2 * RW + q] + res[3 * RW + q]);
+        const double a23 = (res[QP + q] + res[RW + QP + q]) + (res[2 * RW + QP + q] + res[3 * RW + QP + q]);
+        const double dmu = 2.0 * dq * (a1 - mu * w);
+        const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
+        const double dS = -2.0 * dq * dq * dd;
+        if (accumulate) {
+          gmu_g[n * QP + q] += dmu;
+          gS_g[n * QP + q] += dS;
+        } else {
+          gmu_g[n * QP + q] = dmu;
+          gS_g[n * QP + q] = dS;
+        }
+        const double il = 1.0 / lam_g[q];
+        dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
+      } else if (t >= Q && t < QP && !accumulate) {
+        gmu_g[n * QP + t] = 0.0;
+        gS_g[n * QP + t] = 0.0;
+      }
+      if (t == 0) wsum_acc += w;
+      __syncthreads();
     } else {
       __syncthreads();      // hbuf is rewritten at the top of the next iteration
     }
@@ -548,42 +571,44 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
 
   if (FWD) {
     __syncthreads();
-    double* out = a.o.p2_part + (size_t)blockIdx.x * tri;
-    for (int i = t; i < tri; i += RGP_PSI2_TEAM) out[i] = p2acc[i];
+    double* out = p2_part + (size_t)blockIdx.x * tri;
+    for (int i = t; i < tri; i += PSI2_THREADS) out[i] = p2acc[i];
   }
   if (BWD) {
-    if (t < QP) a.o.dlam_part[(size_t)blockIdx.x * QP + t] = (t < a.Q) ? dlam_acc : 0.0;
-    if (t == 0) a.o.wsum_part[blockIdx.x] = wsum_acc;
+    if (t < QP) dlam_part[(size_t)blockIdx.x * QP + t] = (t < Q) ? dlam_acc : 0.0;
+    if (t == 0) wsum_part[blockIdx.x] = wsum_acc;
   }
 }
 
 size_t psi2_num_blocks(rgp_handle h, int64_t N) {
-  // two 128-thread workgroups per CU (LDS holds one packed M x M accumulator each)
+  // two 256-thread workgroups per CU (LDS holds one packed M x M accumulator each; 2 waves per SIMD)
   int64_t b = 2 * (int64_t)h->num_cu;
-  if (b > (N + 1) / 2) b = (N + 1) / 2;
+  if (b > N) b = N;
   return (size_t)(b < 1 ? 1 : b);
 }
+#undef zrow
 
-template <int QP, int NB>
-static void psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Args& a, int nblk) {
+template <int QP>
+static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Args& a, int nblk) {
   const int tri = a.M * (a.M + 1) / 2;
-  size_t lds = (size_t)NB * RGP_PSI2_TEAM + 16;
-  if (fwd) lds += tri;
-  if (bwd) lds += 2 * RED_QC * RED_RS + 2 * QP;
+  size_t lds = (size_t)RGP_PSI2_TEAM;
+  if (fwd) lds += tri + RGP_PSI2_TEAM;
+  if (bwd) lds += 4 * RED_WAVE + 4 * (2 * QP + 8);
   lds *= sizeof(double);
-  if (fwd && bwd) {
-    hipLaunchKernelGGL((psi2_rows_kernel<QP, NB, true, true>), dim3(nblk), dim3(RGP_PSI2_TEAM), lds, s, a.N, a.M, a.Q, a.Zc, a.zd, a.lam,
-                       a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
-                       a.o.accumulate);
-  } else if (fwd) {
-    hipLaunchKernelGGL((psi2_rows_kernel<QP, NB, true, false>), dim3(nblk), dim3(RGP_PSI2_TEAM), lds, s, a.N, a.M, a.Q, a.Zc, a.zd, a.lam,
-                       a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
-                       a.o.accumulate);
-  } else {
-    hipLaunchKernelGGL((psi2_rows_kernel<QP, NB, false, true>), dim3(nblk), dim3(RGP_PSI2_TEAM), lds, s, a.N, a.M, a.Q, a.Zc, a.zd, a.lam,
-                       a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
-                       a.o.accumulate);
-  }
+#define PSI2_LAUNCH(F, B)                                                                                             \
+  do {                                                                                                                \
+    hipError_t e = hipFuncSetAttribute((const void*)psi2_rows_kernel<QP, F, B>,                                       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    if (e != hipSuccess) return e;                                                                                    \
+    hipLaunchKernelGGL((psi2_rows_kernel<QP, F, B>), dim3(nblk), dim3(PSI2_THREADS), lds, s, a.N, a.M, a.Q, a.Zc, a.ZcT, \
+                       a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part,        \
+                       a.o.gmu, a.o.gS, a.o.accumulate);                                                              \
+  } while (0)
+  if (fwd && bwd) PSI2_LAUNCH(true, true);
+  else if (fwd) PSI2_LAUNCH(true, false);
+  else PSI2_LAUNCH(false, true);
+#undef PSI2_LAUNCH
+  return hipSuccess;
 }
 
 rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt,
@@ -591,23 +616,22 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
   if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: M > 128 is not supported by this build");
   if (zt.QP > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: Q > 64 is not supported by this build");
   Psi2Args a{};
-  a.N = N; a.M = M; a.Q = Q; a.Zc = zt.Zc; a.zd = zt.zd; a.lam = zt.lam; a.dLs = dLs;
+  a.N = N; a.M = M; a.Q = Q; a.Zc = zt.Zc; a.ZcT = zt.ZcT; a.zd = zt.zd; a.lam = zt.lam; a.dLs = dLs;
   a.Xmu = rt.Xmu; a.d2 = rt.d2; a.g0 = rt.g0; a.o = out;
   hipStream_t s = h->stream;
-  // rows per thread-pass: two rows share one sweep over z[m'] only while dz+y for both fit the 256 arch VGPRs
-  static const int nb_env = getenv("RGP_PSI2_NB") ? atoi(getenv("RGP_PSI2_NB")) : 0;
-  const int nb = nb_env ? nb_env : (zt.QP <= 16 ? 2 : 1);
-#define PSI2_CASE(qp)                                                         \
-  case qp:                                                                    \
-    if (nb == 2 && qp <= 40) psi2_dispatch<qp, (qp <= 40 ? 2 : 1)>(s, fwd, bwd, a, nblk); \
-    else psi2_dispatch<qp, 1>(s, fwd, bwd, a, nblk);                          \
-    break;
+  hipError_t e = hipSuccess;
   switch (zt.QP) {
-    PSI2_CASE(8) PSI2_CASE(16) PSI2_CASE(24) PSI2_CASE(32) PSI2_CASE(40) PSI2_CASE(48) PSI2_CASE(56) PSI2_CASE(64)
+    case 8:  e = psi2_dispatch<8>(s, fwd, bwd, a, nblk); break;
+    case 16: e = psi2_dispatch<16>(s, fwd, bwd, a, nblk); break;
+    case 24: e = psi2_dispatch<24>(s, fwd, bwd, a, nblk); break;
+    case 32: e = psi2_dispatch<32>(s, fwd, bwd, a, nblk); break;
+    case 40: e = psi2_dispatch<40>(s, fwd, bwd, a, nblk); break;
+    case 48: e = psi2_dispatch<48>(s, fwd, bwd, a, nblk); break;
+    case 56: e = psi2_dispatch<56>(s, fwd, bwd, a, nblk); break;
+    case 64: e = psi2_dispatch<64>(s, fwd, bwd, a, nblk); break;
     default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: unsupported padded Q");
   }
-#undef PSI2_CASE
-  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 launch: ") + hipGetErrorString(e));
   return RGP_OK;
 }

@@ -47,7 +47,7 @@ int main() {
   printf("device %s CUs %d clock %d MHz\n", p.name, cus, p.clockRate / 1000);
   double* out; hipMalloc(&out, sizeof(double) * 256 * cus * 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int wpc = 1; wpc <= 2; ++wpc) {             // 4 or 8 waves per CU
+  for (int wpc = 1; wpc <= 8; wpc *= 2) {             // 4, 8, 16, 32 waves per CU
     const int blocks = cus * wpc, iters = 20000;
     float ms;
     mfma_kernel<<<blocks, 256>>>(out, 100, 1.0, 1.0); hipDeviceSynchronize();
