@@ -208,47 +208,53 @@ struct FinalizeArgs {
   double *gZ, *ginv_l, *gvariance;   // [M x Q], [Q], [1]
 };
 
-__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
-  extern __shared__ double lds[];
+// grid = M workgroups (one inducing row each) of 64 x 4 threads: lane q, 4 slices of m'.
+// Writes gZ[m,:], the per-row dinv_l contributions dlrow[m,:] and the per-row sum of dKmm*K.
+__global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, double* __restrict__ dlrow,
+                                                             double* __restrict__ gsum_row) {
+  __shared__ double sm[2][4][64];
   __shared__ double scratch[16];
-  double* dlrow = lds;        // [M x QP]
-  const int M = a.M, Q = a.Q, QP = a.QP, t = threadIdx.x;
-  const double var = a.variance[0];
-  double gsum = 0.0;
-  for (int i = t; i < M * QP; i += blockDim.x) {
-    const int m = i / QP, q = i % QP;
-    double dz = 0.0, dl = 0.0;
+  const int M = a.M, Q = a.Q, QP = a.QP;
+  const int m = blockIdx.x, q = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  double s1 = 0.0, s2 = 0.0, gs = 0.0;
+  const double zm = (q < QP) ? a.Zc[m * QP + q] : 0.0;
+  for (int mp = sl; mp < M; mp += 4) {
+    double gk = 0.0, gkT = 0.0, ws = 0.0;
+    if (a.dKmm) {
+      const double k1 = a.Kj[m * M + mp] - (m == mp ? RGP_JITTER : 0.0);
+      gk = a.dKmm[m * M + mp] * k1;
+      gkT = a.dKmm[mp * M + m] * k1;
+      if (q == 0) gs += gk;
+    }
+    if (a.dLs) ws = a.dLs[m * M + mp] * a.psi2[m * M + mp];
+    if (q < QP) {
+      const double df = zm - a.Zc[mp * QP + q];
+      s1 += (gk + gkT + ws) * df;
+      s2 += (gk + 0.5 * ws) * df * df;
+    }
+  }
+  sm[0][sl][q] = s1;
+  sm[1][sl][q] = s2;
+  const double gtot = block_sum(gs, scratch);
+  __syncthreads();
+  if (sl == 0 && q < QP) {
+    s1 = (sm[0][0][q] + sm[0][1][q]) + (sm[0][2][q] + sm[0][3][q]);
+    s2 = (sm[1][0][q] + sm[1][1][q]) + (sm[1][2][q] + sm[1][3][q]);
     if (q < Q) {
-      const double zm = a.Zc[m * QP + q];
-      double s1 = 0.0, s2 = 0.0;
-      for (int mp = 0; mp < M; ++mp) {
-        double gk = 0.0, gkT = 0.0, ws = 0.0;
-        if (a.dKmm) {
-          const double k1 = a.Kj[m * M + mp] - (m == mp ? RGP_JITTER : 0.0);
-          gk = a.dKmm[m * M + mp] * k1;
-          gkT = a.dKmm[mp * M + m] * k1;
-        }
-        if (a.dLs) ws = a.dLs[m * M + mp] * a.psi2[m * M + mp];
-        const double df = zm - a.Zc[mp * QP + q];
-        s1 += (gk + gkT + ws) * df;
-        s2 += (gk + 0.5 * ws) * df * df;
-      }
-      dz = -a.lam[q] * s1;
-      dl = -0.5 * s2;
+      double dz = -a.lam[q] * s1;
       if (a.dz1) dz += a.dz1[m * QP + q];
       if (a.dz2) dz += a.dz2[q * RGP_PSI2_TEAM + m];
       a.gZ[m * Q + q] = dz;
     }
-    dlrow[i] = dl;
+    dlrow[m * QP + q] = (q < Q) ? -0.5 * s2 : 0.0;
   }
-  if (a.dKmm) {
-    for (int i = t; i < M * M; i += blockDim.x) {
-      const int m = i / M, mp = i % M;
-      gsum += a.dKmm[i] * (a.Kj[i] - (m == mp ? RGP_JITTER : 0.0));
-    }
-  }
-  gsum = block_sum(gsum, scratch);
-  __syncthreads();
+  if (threadIdx.x == 0) gsum_row[m] = gtot;
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a, const double* __restrict__ dlrow,
+                                                        const double* __restrict__ gsum_row) {
+  const int M = a.M, Q = a.Q, QP = a.QP, t = threadIdx.x;
+  const double var = a.variance[0];
   if (t < Q) {
     double s = 0.0;
     for (int m = 0; m < M; ++m) s += dlrow[m * QP + t];
@@ -257,12 +263,19 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a) {
     a.ginv_l[t] = s;
   }
   if (t == 0) {
+    double gsum = 0.0;
+    for (int m = 0; m < M; ++m) gsum += gsum_row[m];
     double g = a.psi0_coef + gsum / var;
     if (a.psi0_dev) g += a.psi0_dev[0] * a.psi0_dev_scale;
     if (a.lsum1) g += a.lsum1[0] / var;
     if (a.wsum2) g += 2.0 * a.wsum2[0] / var;
     a.gvariance[0] = g;
   }
+}
+
+static void launch_finalize(hipStream_t s, const FinalizeArgs& f, double* dlrow, double* gsum_row) {
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(f.M), dim3(256), 0, s, f, dlrow, gsum_row);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, f, dlrow, gsum_row);
 }
 
 // -D beta N / 2 (= sum_n dL_dpsi0, svi_vardtc.py:162) as a device scalar
@@ -397,7 +410,7 @@ struct LayerWs {
   double *psi1, *Lp, *gmu, *gS, *Ym, *Yv, *dYm;
   double *p2_part, *p2_tri, *psi2, *dLs;
   double *dz1_part, *dz1, *dz2_part, *dz2, *dlam1_part, *dlam1, *dlam2_part, *dlam2, *lsum1_part, *lsum1, *wsum2_part, *wsum2;
-  double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part;
+  double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
   int64_t *row_off, *own_pre, *up_pre;
   int nblk1, nblk2;
 };
@@ -432,6 +445,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
   L.psi1Y_part = ws.take<double>((size_t)L.nblk1 * (D > 0 ? D : 1) * M); L.psi1Y = ws.take<double>((size_t)(D > 0 ? D : 1) * M);
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
+  L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
   if (ch) svi_chain_carve(*ch, ws);
   return ws.off;
@@ -547,7 +561,7 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
   f.lsum1 = dL_dpsi1 ? L.lsum1 : nullptr; f.wsum2 = dL_dpsi2 ? L.wsum2 : nullptr;
   f.psi0_coef = dL_dpsi0_sum; f.psi0_dev = nullptr; f.psi0_dev_scale = 0.0;
   f.gZ = dZ; f.ginv_l = dinv_l; f.gvariance = dvar;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), (size_t)M * QP * sizeof(double), s, f);
+  launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
   const int64_t nq = N * Q;
   hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, N, Q, QP, L.gmu, dmu);
   hipLaunchKernelGGL(unpad_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, N, Q, QP, L.gS, dS);
@@ -674,7 +688,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
     f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
     f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), (size_t)M * QP * sizeof(double), s, f);
+    launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
   }
 
   // latent gradients

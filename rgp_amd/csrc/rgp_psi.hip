@@ -639,19 +639,31 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
 // ------------------------------------------------------------------------------------------------------------------
 // deterministic reduction of per-block partials
 // ------------------------------------------------------------------------------------------------------------------
+// 32 elements x 8 partial groups per workgroup: group g sums partials g, g+8, ... in order, then the 8 group sums are
+// added in fixed order -> deterministic and 8x more parallel than one thread per element.
 __global__ void __launch_bounds__(256) reduce_kernel(int nblk, int64_t len, int64_t stride, const double* __restrict__ part,
                                                       double* __restrict__ out, double scale, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len) return;
+  __shared__ double sm[8][33];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
   double s = 0.0;
-  for (int g = 0; g < nblk; ++g) s += part[(size_t)g * stride + i];
-  s *= scale;
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < len) {
+    for (int b = g; b < nblk; b += 8) s += part[(size_t)b * stride + i];
+  }
+  sm[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < len) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += sm[k][e];
+    tot *= scale;
+    out[i] = accumulate ? out[i] + tot : tot;
+  }
 }
 
 void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const double* part, double* out, double scale,
                    int accumulate) {
-  const int blocks = (int)((len + 255) / 256);
+  const int blocks = (int)((len + 31) / 32);
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(256), 0, s, nblk, len, stride, part, out, scale, accumulate);
 }
 
