@@ -21,3 +21,20 @@ size_t svi_chain_ws_doubles(int M, int D);
 void svi_chain_carve(SviChain& c, WsAlloc& ws);
 rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c);
 rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c);
+
+// ---- collapsed (Titsias) bound, autoreg/inference/vardtc.py:88-208 ------------------------------------------------
+struct VarDtcChain {
+  int64_t N; int M, D; int y_uncertain;
+  // inputs (device)
+  const double *Kj, *noise;
+  const double *psi0sum, *psi1Y, *psi2, *yry;       // psi1Y: D x M (unscaled)
+  const double *PsiR;                               // M x M: sum_n r_n^2 psi1_n^T psi1_n (uncertain outputs only)
+  // workspace
+  double *Linv, *A, *LLinv, *Li, *G2, *T1, *T2, *T3, *C, *R, *dKmm, *dLdpsi2, *bT, *vT, *Vb;
+  double *scal, *bound, *dthetaL, *beta;
+  double *winv;                                      // optional output
+  int* status;
+};
+size_t vardtc_chain_ws_doubles(int M, int D);
+void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws);
+rgp_status launch_vardtc_chain(rgp_handle h, const VarDtcChain& c);

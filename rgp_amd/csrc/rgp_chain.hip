@@ -258,3 +258,96 @@ rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c) {
   hipLaunchKernelGGL(svi_chain_post_kernel, dim3(1), dim3(CH_THREADS), 0, h->stream, c);
   return RGP_OK;
 }
+
+// ==================================================================================================================
+// collapsed bound (VarDTC.inference, autoreg/inference/vardtc.py:88-208), given the statistics.
+// With Li = L^-1 = LL^-1 Lm^-1 (L = Lm LL, vardtc.py:126):
+//   b^T = beta Li psi1Y^T, v^T = Li^T b^T;   C = b^T b (+ beta^2 Li PsiR Li^T for uncertain outputs, :136-138)
+//   R = 1/2 Lm^-T [D I - LL^-T (C + D I) LL^-1] Lm^-1 (:140-141);  dL_dpsi2 = beta R;  dL_dKmm = R - D/2 Lm^-T A Lm^-1
+// Outputs consumed by the row kernels: vT (M x D), G2 = Li^T Li (M x M), beta.
+// ==================================================================================================================
+__global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c) {
+  extern __shared__ double lds[];
+  __shared__ double scratch[16];
+  const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
+  const double Dd = (double)D, Nd = (double)c.N;
+  const double beta = 1.0 / fmax(c.noise[0], 1e-6);                 // vardtc.py:102
+  copy_in(lds, ld, c.Kj, M);
+  lds_chol(lds, M, ld, c.status);
+  lds_trtri(lds, M, ld);
+  copy_out(c.Linv, lds, ld, M);
+  // A = beta Linv psi2 Linv^T ; Lambda = I + A ; LL = chol(Lambda)          (:120-125)
+  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M);
+  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M);
+  for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.A[i] + ((i / M == i % M) ? 1.0 : 0.0);
+  __syncthreads();
+  copy_in(lds, ld, c.T1, M);
+  lds_chol(lds, M, ld, c.status);
+  const double ldLL = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
+  lds_trtri(lds, M, ld);
+  copy_out(c.LLinv, lds, ld, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.LLinv, M, c.Linv, M, 0.0, c.Li, M);          // Li = L^-1
+  wg_gemm<true, false>(M, M, M, 1.0, c.Li, M, c.Li, M, 0.0, c.G2, M);                // G2 = Li^T Li
+  wg_gemm<false, true>(M, D, M, beta, c.Li, M, c.psi1Y, M, 0.0, c.bT, D);            // b^T (M x D)   (:130)
+  wg_gemm<true, false>(M, D, M, 1.0, c.Li, M, c.bT, D, 0.0, c.vT, D);                // v^T           (:132)
+  wg_gemm<false, true>(M, M, D, 1.0, c.bT, D, c.bT, D, 0.0, c.C, M);                 // C = b^T b     (:133)
+  if (c.y_uncertain) {
+    wg_gemm<false, false>(M, M, M, 1.0, c.Li, M, c.PsiR, M, 0.0, c.T1, M);
+    wg_gemm<false, true>(M, M, M, beta * beta, c.T1, M, c.Li, M, 1.0, c.C, M);       // + c^T c       (:137-138)
+  }
+  double trC = 0.0, trA = 0.0, sR = 0.0;
+  for (int i = t; i < M; i += blockDim.x) { trC += c.C[i * M + i]; trA += c.A[i * M + i]; }
+  trC = block_sum(trC, scratch); trA = block_sum(trA, scratch);
+  // R = 1/2 Linv^T [D I - LLinv^T (C + D I) LLinv] Linv
+  for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.C[i] + ((i / M == i % M) ? Dd : 0.0);
+  __syncthreads();
+  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.LLinv, M, 0.0, c.T2, M);
+  wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.T2, M, 0.0, c.T3, M);
+  for (int i = t; i < M * M; i += blockDim.x) c.T3[i] += ((i / M == i % M) ? Dd : 0.0);
+  __syncthreads();
+  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T2, M);
+  wg_gemm<true, false>(M, M, M, 0.5, c.Linv, M, c.T2, M, 0.0, c.R, M);
+  // dL_dKmm = R - D/2 Linv^T A Linv                                                    (:155)
+  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T2, M);
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.T3, M);
+  for (int i = t; i < M * M; i += blockDim.x) {
+    c.dKmm[i] = c.R[i] - 0.5 * Dd * c.T3[i];
+    c.dLdpsi2[i] = beta * c.R[i];
+    sR += c.R[i] * beta * c.psi2[i];
+  }
+  sR = block_sum(sR, scratch);
+  if (c.winv) {                                                                         // (:161)
+    wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.LLinv, M, 0.0, c.T1, M);
+    for (int i = t; i < M; i += blockDim.x) c.T1[i * M + i] += 1.0;
+    __syncthreads();
+    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M);
+    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M);
+  }
+  if (t == 0) {
+    const double psi0b = beta * c.psi0sum[0], YRY = beta * c.yry[0];
+    const double bbt = trC;                                       // ||b||^2 (+ ||c||^2) = tr C
+    c.bound[0] = -0.5 * (Dd * (Nd * LOG_2PI - Nd * log(beta) + psi0b - trA) + YRY - bbt) - Dd * ldLL;     // (:148-149)
+    c.dthetaL[0] = 0.5 * (YRY * beta + beta * Dd * psi0b - Nd * Dd * beta) - beta * sR - beta * trC;   // (:168)
+    c.beta[0] = beta;
+  }
+}
+
+size_t vardtc_chain_ws_doubles(int M, int D) { return (size_t)14 * M * M + 3 * (size_t)M * D + 64; }
+
+void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws) {
+  const size_t mm = (size_t)c.M * c.M, md = (size_t)c.M * c.D;
+  c.Linv = ws.take<double>(mm); c.A = ws.take<double>(mm); c.LLinv = ws.take<double>(mm); c.Li = ws.take<double>(mm);
+  c.G2 = ws.take<double>(mm); c.T1 = ws.take<double>(mm); c.T2 = ws.take<double>(mm); c.T3 = ws.take<double>(mm);
+  c.C = ws.take<double>(mm); c.R = ws.take<double>(mm); c.dKmm = ws.take<double>(mm); c.dLdpsi2 = ws.take<double>(mm);
+  c.bT = ws.take<double>(md); c.vT = ws.take<double>(md); c.Vb = ws.take<double>(md);
+  c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1); c.beta = ws.take<double>(1);
+}
+
+rgp_status launch_vardtc_chain(rgp_handle h, const VarDtcChain& c) {
+  if (c.M > 140) return rgp_fail(h, RGP_ERR_BAD_ARG, "vardtc chain: M > 140 needs the blocked factorisation (not in this build)");
+  const size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)vardtc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("vardtc chain LDS attr: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(vardtc_chain_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
+  return RGP_OK;
+}

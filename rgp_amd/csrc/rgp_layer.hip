@@ -144,12 +144,14 @@ __global__ void __launch_bounds__(256) svi_rows_kernel(int64_t N, int M, int D, 
 #define CM_TILE 32
 #define CM_MAXK 32
 __global__ void __launch_bounds__(256) colmm_kernel(int64_t N, int K, int P, const double* __restrict__ A,
-                                                     const double* __restrict__ B, double* __restrict__ part) {
+                                                     const double* __restrict__ B, const double* __restrict__ w,
+                                                     double* __restrict__ part) {
   extern __shared__ double lds[];
   double* a_s = lds;                          // [CM_TILE x K]
   double* b_s = a_s + (size_t)CM_TILE * K;    // [CM_TILE x P]
   const int G = blockDim.x / P;
   const int p = threadIdx.x % P, g = threadIdx.x / P;
+  const int k0 = blockIdx.y * G * CM_MAXK;    // this workgroup's chunk of output rows k
   const bool act = g < G;
   double acc[CM_MAXK];
 #pragma unroll
@@ -160,14 +162,14 @@ __global__ void __launch_bounds__(256) colmm_kernel(int64_t N, int K, int P, con
     const int nr = (int)((r1 - rb) < CM_TILE ? (r1 - rb) : CM_TILE);
     __syncthreads();
     for (int i = threadIdx.x; i < nr * K; i += blockDim.x) a_s[i] = A[rb * K + i];
-    for (int i = threadIdx.x; i < nr * P; i += blockDim.x) b_s[i] = B[rb * P + i];
+    for (int i = threadIdx.x; i < nr * P; i += blockDim.x) b_s[i] = B[rb * P + i] * (w ? w[rb + i / P] : 1.0);
     __syncthreads();
     if (act) {
       for (int r = 0; r < nr; ++r) {
         const double b = b_s[r * P + p];
 #pragma unroll
         for (int k = 0; k < CM_MAXK; ++k) {
-          const int kk = g + k * G;
+          const int kk = k0 + g + k * G;
           if (kk < K) acc[k] += a_s[r * K + kk] * b;
         }
       }
@@ -176,8 +178,73 @@ __global__ void __launch_bounds__(256) colmm_kernel(int64_t N, int K, int P, con
   if (act) {
 #pragma unroll
     for (int k = 0; k < CM_MAXK; ++k) {
-      const int kk = g + k * G;
+      const int kk = k0 + g + k * G;
       if (kk < K) part[((size_t)blockIdx.x * K + kk) * P + p] = acc[k];
+    }
+  }
+}
+
+// out [K x P] = sum_n w_n A[n,:]^T B[n,:]   (fixed-order reduction of per-workgroup partials)
+static void launch_colmm(hipStream_t s, int64_t N, int K, int P, const double* A, const double* B, const double* w,
+                         double* part, double* out, int nblk) {
+  const int G = 256 / P;
+  const int kchunks = (K + G * CM_MAXK - 1) / (G * CM_MAXK);
+  const size_t lds = ((size_t)CM_TILE * K + (size_t)CM_TILE * P) * sizeof(double);
+  hipLaunchKernelGGL(colmm_kernel, dim3(nblk, kchunks), dim3(256), lds, s, N, K, P, A, B, w, part);
+  launch_reduce(s, nblk, (int64_t)K * P, (int64_t)K * P, part, out, 1.0, 0);
+}
+
+__global__ void __launch_bounds__(256) rowsum_kernel(int64_t N, int D, const double* __restrict__ X, double* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) s += X[r * D + d];
+  out[r] = s;
+}
+
+// Row part of the collapsed bound (vardtc.py:177-205), one wave per row:
+//   T = psi1 G2 (G2 = L^-T L^-1);  dL_dpsi1 = beta Ym v + beta^2 r^2 T   (r^2 = sum_d Yvar; second term only for
+//   uncertain outputs);  dL_dYmean = -beta Ym + beta psi1 v^T;  dL_dYvar = -beta/2 + beta^2/2 T.psi1   (shape (N,))
+__global__ void __launch_bounds__(256) vardtc_rows_kernel(int64_t N, int M, int D, int y_unc, const double* __restrict__ Ym,
+                                                           const double* __restrict__ r2, const double* __restrict__ psi1,
+                                                           const double* __restrict__ vT, const double* __restrict__ G2,
+                                                           const double* __restrict__ beta_p, double* __restrict__ dLdpsi1,
+                                                           double* __restrict__ dYm, double* __restrict__ dYvar) {
+  extern __shared__ double lds[];
+  const int DS = D + 1, MS = M + 1;
+  double* vs = lds;                                   // [M x DS]
+  double* gs = vs + (size_t)M * DS;                   // [M x MS]   (uncertain outputs only)
+  for (int i = threadIdx.x; i < M * D; i += blockDim.x) vs[(i / D) * DS + (i % D)] = vT[i];
+  if (y_unc) for (int i = threadIdx.x; i < M * M; i += blockDim.x) gs[(i / M) * MS + (i % M)] = G2[i];
+  __syncthreads();
+  const double beta = beta_p[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < N; r += (int64_t)gridDim.x * wpb) {
+    const double* __restrict__ y = Ym + r * D;
+    const double* __restrict__ p = psi1 + r * M;
+    const double rr = y_unc ? r2[r] : 0.0;
+    double tp = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      double acc = 0.0;
+      for (int d = 0; d < D; ++d) acc += y[d] * vs[m * DS + d];
+      acc *= beta;
+      if (y_unc) {
+        double tt = 0.0;
+        for (int k = 0; k < M; ++k) tt += p[k] * gs[k * MS + m];
+        acc += beta * beta * rr * tt;
+        tp += tt * p[m];
+      }
+      dLdpsi1[r * M + m] = acc;
+    }
+    if (y_unc) {
+      tp = wave_sum(tp);
+      if (lane == 0) dYvar[r] = -0.5 * beta + 0.5 * beta * beta * tp;
+      for (int d = lane; d < D; d += 64) {
+        double acc = 0.0;
+        for (int m = 0; m < M; ++m) acc += p[m] * vs[m * DS + d];
+        dYm[r * D + d] = -beta * y[d] + beta * acc;
+      }
     }
   }
 }
@@ -282,6 +349,9 @@ static void launch_finalize(hipStream_t s, const FinalizeArgs& f, double* dlrow,
 __global__ void psi0_coef_kernel(int64_t N, int D, const double* noise, double* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = -0.5 * (double)D * (double)N / noise[0];
 }
+__global__ void psi0_coef_beta_kernel(int64_t N, int D, const double* beta, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = -0.5 * (double)D * (double)N * beta[0];
+}
 
 __global__ void prefix_kernel(int n_seq, const int64_t* __restrict__ len, int64_t* pre) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -307,6 +377,7 @@ struct LatentArgs {
   WindowSpec w; int QP; int64_t own_rows;
   const int64_t* own_pre;
   const double *gmu, *gS, *dYm, *noise;
+  const double* dYvar_row;        // collapsed bound: (N,) array (vardtc.py:205); null -> -beta/2 (svi_vardtc.py:193)
   double *g_own_mean, *g_own_var, *elbo_part;
 };
 
@@ -328,7 +399,7 @@ __global__ void __launch_bounds__(256) own_latent_kernel(LatentArgs a) {
     if (tt >= Xw) {
       const int64_t r = a.w.row_off[s] + (tt - Xw);
       gm = a.dYm[r * Xd + d];
-      gv = -0.5 * beta + 0.5 / S;                                   // svi_vardtc.py:193 + variational.py:12
+      gv = (a.dYvar_row ? a.dYvar_row[r] : -0.5 * beta) + 0.5 / S;   // svi_vardtc.py:193 / vardtc.py:205 + variational.py:12
       el += 0.5 * (1.0 + 1.8378770664093453 + log(S));              // -NormalEntropy.comp_value
     } else {
       gm = -mu;                                                     // variational.py:23
@@ -411,6 +482,7 @@ struct LayerWs {
   double *p2_part, *p2_tri, *psi2, *dLs;
   double *dz1_part, *dz1, *dz2_part, *dz2, *dlam1_part, *dlam1, *dlam2_part, *dlam2, *lsum1_part, *lsum1, *wsum2_part, *wsum2;
   double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
+  double *r2, *dYvar_row, *PsiR_part, *PsiR;      // collapsed bound only
   int64_t *row_off, *own_pre, *up_pre;
   int nblk1, nblk2;
 };
@@ -418,7 +490,8 @@ struct LayerWs {
 #define NBLK1 512          // workgroups of the psi1-side reductions
 #define LAT_BLOCKS 1024
 
-static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int D, int n_seq, LayerWs& L, SviChain* ch) {
+static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int D, int n_seq, LayerWs& L, SviChain* ch,
+                          VarDtcChain* vc = nullptr) {
   WsAlloc ws(base);
   const int QP = round_up(Q, 8);
   const size_t nq = (size_t)N * QP, nm = (size_t)N * M, nd = (size_t)N * (D > 0 ? D : 1);
@@ -448,6 +521,11 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
   if (ch) svi_chain_carve(*ch, ws);
+  if (vc) {
+    L.r2 = ws.take<double>(N); L.dYvar_row = ws.take<double>(N);
+    L.PsiR_part = ws.take<double>((size_t)L.nblk1 * M * M); L.PsiR = ws.take<double>((size_t)M * M);
+    vardtc_chain_carve(*vc, ws);
+  }
   return ws.off;
 }
 
@@ -597,12 +675,124 @@ extern "C" rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, doubl
 }
 
 // ==================================================================================================================
+// collapsed-bound layer step (VarDTC.inference, vardtc.py:88-208): dL/dpsi2 depends on the statistics, so the psi2
+// kernel runs twice (forward sum, then backward with recomputation) around the M x M chain.
+// ==================================================================================================================
+static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
+  const int M = in->M, D = in->D;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  const int64_t N = in->N;
+  rgp_status st = check_geometry(h, N, M, Q);
+  if (st) return st;
+  if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
+  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
+  LayerWs L;
+  VarDtcChain c{};
+  c.N = N; c.M = M; c.D = D; c.y_uncertain = in->y_uncertain;
+  const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, nullptr, &c);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  carve_layer(h, h->ws, N, M, Q, D, in->n_seq, L, nullptr, &c);
+  hipStream_t s = h->stream;
+  const int QP = L.zt.QP;
+  const int tri = M * (M + 1) / 2;
+
+  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
+  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
+  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+  WindowSpec w{};
+  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
+  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
+  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
+  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+
+  // statistics (vardtc.py:54-86)
+  launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
+  if (D > ((256 / M) > 0 ? (256 / M) : 1) * CM_MAXK * 64) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large");
+  launch_colmm(s, N, D, M, L.Ym, L.psi1, nullptr, L.psi1Y_part, L.psi1Y, L.nblk1);
+  if (in->y_uncertain) {
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, D, L.Yv, L.r2);
+    launch_colmm(s, N, M, M, L.psi1, L.psi1, L.r2, L.PsiR_part, L.PsiR, L.nblk1);
+  }
+  {
+    Psi2Out o{};
+    o.p2_part = L.p2_part;
+    if ((st = launch_psi2(h, true, false, N, M, Q, L.zt, L.rt, nullptr, o, L.nblk2))) return st;
+    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_unpack_tri(s, M, L.p2_tri, L.psi2);
+  }
+  hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
+
+  // M x M algebra
+  c.Kj = L.zt.Kuu; c.noise = in->noise; c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
+  c.PsiR = L.PsiR; c.winv = out->woodbury_inv; c.status = h->status;
+  if ((st = launch_vardtc_chain(h, c))) return st;
+  hipLaunchKernelGGL(psi0_coef_beta_kernel, dim3(1), dim3(64), 0, s, N, D, c.beta, L.psi0coef);
+
+  // row gradients
+  {
+    const size_t lds = ((size_t)M * (D + 1) + (in->y_uncertain ? (size_t)M * (M + 1) : 0)) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)vardtc_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, "vardtc rows LDS attr");
+    int64_t b = (N + 3) / 4; if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(vardtc_rows_kernel, dim3((unsigned)b), dim3(256), lds, s, N, M, D, in->y_uncertain, L.Ym, L.r2, L.psi1,
+                       c.vT, c.G2, c.beta, L.Lp, L.dYm, L.dYvar_row);
+  }
+  launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
+  launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
+  launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
+  launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
+  launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+  hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
+  {
+    Psi2Out o{};
+    o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
+    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
+    if ((st = launch_psi2(h, false, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
+    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+  }
+  {
+    FinalizeArgs f{};
+    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
+    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
+    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
+    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
+    launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
+  }
+  int npart = 0;
+  if (in->y_uncertain) {
+    LatentArgs a{};
+    a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
+    a.noise = in->noise; a.dYvar_row = L.dYvar_row; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var;
+    a.elbo_part = L.elbo_part;
+    hipLaunchKernelGGL(own_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+    npart = LAT_BLOCKS;
+  }
+  if (out->g_up_mean && in->U_win > 0) {
+    UpArgs a{};
+    a.w = w; a.QP = QP; a.up_rows = in->up_rows; a.up_pre = L.up_pre; a.gmu = L.gmu; a.gS = L.gS;
+    a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
+    hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
+                     out->gnoise);
+  if (out->woodbury_vector)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.vT, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return last_launch(h, "rgp_layer_step(vardtc)");
+}
+
+// ==================================================================================================================
 // the fused layer step
 // ==================================================================================================================
 extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
   if (!h || !in || !out) return RGP_ERR_BAD_ARG;
-  if (in->mode != RGP_MODE_SVI)
-    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: only RGP_MODE_SVI runs on the device in this build");
+  if (in->mode == RGP_MODE_VARDTC) return vardtc_layer_step(h, in, out);
+  if (in->mode != RGP_MODE_SVI) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: unknown mode");
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
@@ -648,10 +838,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
                        L.Lp /* dLdpsi1, overwritten in place by Lp below */, in->y_uncertain ? L.dYm : nullptr);
   }
   {
-    if (D > (256 / M) * CM_MAXK) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large for the psi1Y pass of this build");
-    const size_t lds = ((size_t)CM_TILE * D + (size_t)CM_TILE * M) * sizeof(double);
-    hipLaunchKernelGGL(colmm_kernel, dim3(L.nblk1), dim3(256), lds, s, N, D, M, L.Ym, L.psi1, L.psi1Y_part);
-    launch_reduce(s, L.nblk1, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
+    launch_colmm(s, N, D, M, L.Ym, L.psi1, nullptr, L.psi1Y_part, L.psi1Y, L.nblk1);
   }
   launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
   launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
@@ -696,7 +883,8 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (in->y_uncertain) {
     LatentArgs a{};
     a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
-    a.noise = in->noise; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var; a.elbo_part = L.elbo_part;
+    a.noise = in->noise; a.dYvar_row = nullptr; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var;
+    a.elbo_part = L.elbo_part;
     hipLaunchKernelGGL(own_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
     npart = LAT_BLOCKS;
   }

@@ -17,26 +17,27 @@ def make_data(n_seq, T, u_dim=2, y_dim=3, seed=0, ragged=False):
 
 
 def build_pair(n_seq=3, T=14, wins=(0, 3, 3), nDims=(3, 2, 3), M=4, U_win=2, seed=0, ragged=False, n_total=None,
-               u_dim=2, y_dim=3):
+               u_dim=2, y_dim=3, inference='svi'):
     from oracle import model as om
     from rgp_amd.model import DeepAutoreg
     U, Y = make_data(n_seq, T, u_dim, y_dim, seed, ragged)
     o = om.DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
-                       inference_method='svi', n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=False)
+                       inference_method=inference, n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=False)
     rng = np.random.default_rng(seed + 2)
     for i in o.order:
         p = o.P[i]
         p.inv_l[:] = 0.3 + rng.random(p.inv_l.shape)
         p.variance = 0.7 + rng.random()
         p.noise = 0.1 + 0.3 * rng.random()
-        p.qU_W[:] = rng.standard_normal(p.qU_W.shape) * 0.2
-        p.qU_a = 0.3
+        if inference == 'svi':
+            p.qU_W[:] = rng.standard_normal(p.qU_W.shape) * 0.2
+            p.qU_a = 0.3
     for i in range(1, len(wins)):
         for s in range(n_seq):
             o.Xvar[i][s][:] = 0.02 + 0.1 * rng.random(o.Xvar[i][s].shape)
             o.Xmean[i][s][:] += 0.1 * rng.standard_normal(o.Xmean[i][s].shape)
     g = DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
-                    inference_method='svi', mb_inf_tot_data_size=n_total, seed=seed)
+                    inference_method=inference, mb_inf_tot_data_size=n_total, seed=seed)
     g.load_from_oracle(o)
     return o, g
 
@@ -65,6 +66,32 @@ def compare(o, g, seqs=None, rtol=1e-9):
 def test_elbo_and_gradients_match_oracle(cfg):
     o, g = build_pair(**cfg)
     compare(o, g)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(),
+    dict(wins=(0, 3), nDims=(3, 2), n_seq=2),
+    dict(ragged=True, n_seq=4),
+    dict(wins=(0, 10), nDims=(1, 1), n_seq=1, T=120, M=20, U_win=10, u_dim=1, y_dim=1),      # Actuator-like (config 1 geometry)
+    dict(wins=(0, 20, 20), nDims=(1, 1, 1), n_seq=1, T=150, M=50, U_win=20, u_dim=1, y_dim=1),   # Ballbeam-like (config 2)
+])
+def test_collapsed_bound_matches_oracle(cfg):
+    """VarDTC (autoreg/inference/vardtc.py) on the device: ELBO and every gradient vs the oracle."""
+    o, g = build_pair(inference=None, **cfg)
+    compare(o, g)
+
+
+def test_collapsed_bound_checkgrad_device():
+    o, g = build_pair(n_seq=2, T=10, inference=None)
+    x0 = g.get_optimizer_array()
+    f0, g0 = g.objective_and_grad(x0)
+    rng = np.random.default_rng(4)
+    eps = 1e-6
+    for j in rng.choice(x0.size, size=30, replace=False):
+        xp = x0.copy(); xp[j] += eps
+        xm = x0.copy(); xm[j] -= eps
+        num = (g.objective_and_grad(xp)[0] - g.objective_and_grad(xm)[0]) / (2 * eps)
+        assert abs(num - g0[j]) <= 1e-5 * max(1.0, abs(num)), (j, num, g0[j])
 
 
 def test_minibatch_subset_permutation_additivity():
