@@ -128,6 +128,18 @@ rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, double qU_ratio,
                          double* logL_minus_KL, double* dL_dKmm, double* dL_dpsi2, double* Kinv_mu,
                          double* dL_dthetaL, double* gqU_m, double* gqU_W, double* gqU_a, double* woodbury_inv);
 
+/* ---- free-run prediction with moment matching (Layer.freerun, autoreg/layers.py:1537-1571 + GPy _raw_predict) ------
+ * For each of n_seq independent sequences: X[0..X_win) = init (or N(0,1) when init_* == NULL, layers.py:1545), then for
+ * n = 0..steps-1 the input row [X[n..n+X_win) | U[u_skip+n .. u_skip+n+U_win)] (means AND variances) is pushed through
+ * the layer's posterior (woodbury_inv M x M, woodbury_vector M x D from rgp_layer_step) and the predictive mean/variance
+ * become X[X_win+n] (variance clipped at 1e-15; <= 0 -> 1e-10, layers.py:1570).  X_dim == D.
+ * Layouts: init_* [n_seq][X_win*D]; U_* [n_seq][u_rows][U_dim] (U_var NULL -> u_var_const); X_* [n_seq][X_win+steps][D]. */
+rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_win, int U_win, int U_dim, int steps,
+                       const double* Z, const double* variance, const double* inv_l, const double* woodbury_inv,
+                       const double* woodbury_vector, const double* init_mean, const double* init_var,
+                       const double* U_mean, const double* U_var, double u_var_const, int64_t u_rows, int64_t u_skip,
+                       double* X_mean, double* X_var);
+
 /* ---- optimiser step on device (the outer SVI loop's Adam; positive parameters live in softplus space) -------- */
 /* x, m, v: n doubles of optimiser-space parameter and Adam moments; g: gradient w.r.t. the CONSTRAINED value p;
  * positive[i] != 0 -> p = softplus(x) and the chain factor 1-exp(-p) is applied (paramz Logexp).  The new constrained

@@ -49,6 +49,7 @@ SYMBOLS = {
     'rgp_psi_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double,
                                    c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     'rgp_svi_chain': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double] + [c_dp] * 18),
+    'rgp_freerun': (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [c_dp] * 9 + [C.c_double, C.c_int64, C.c_int64, c_dp, c_dp]),
     'rgp_adam_step': (C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_void_p, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int64]),
 }

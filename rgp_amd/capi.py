@@ -113,6 +113,15 @@ class Handle(object):
     def layer_step(self, lin, lout):
         self._check(self.lib.rgp_layer_step(self.h, C.byref(lin), C.byref(lout)))
 
+    def freerun(self, n_seq, M, D, X_win, U_win, U_dim, steps, Z, variance, inv_l, winv, wvec, init_mean, init_var,
+                U_mean, U_var, u_var_const, u_rows, u_skip):
+        Xm = self.new(n_seq, X_win + steps, D)
+        Xv = self.new(n_seq, X_win + steps, D)
+        self._check(self.lib.rgp_freerun(self.h, n_seq, M, D, X_win, U_win, U_dim, steps, _p(Z), _p(variance), _p(inv_l),
+                                         _p(winv), _p(wvec), _p(init_mean), _p(init_var), _p(U_mean), _p(U_var),
+                                         float(u_var_const), int(u_rows), int(u_skip), _p(Xm), _p(Xv)))
+        return Xm, Xv
+
     def adam_step(self, x, p, g, m, v, positive, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         n = x.numel()
         self._check(self.lib.rgp_adam_step(self.h, n, _p(x), _p(p), _p(g), _p(m), _p(v),

@@ -458,6 +458,34 @@ class DeepAutoreg(object):
         return elbo
 
     # ------------------------------------------------------------------------------------------------------------
+    # prediction: top-down free-run cascade with moment matching (model.py:725-740, layers.py:1537-1571)
+    # ------------------------------------------------------------------------------------------------------------
+    def freerun(self, U, init_Xs=None):
+        """Free simulation for control signal(s) ``U`` ((T, D_u) array or a list of equal-length arrays), using the
+        posterior of the last ``evaluate``/``log_likelihood`` call.  Returns, per layer (top first), a pair of device
+        tensors (mean, variance) of shape (n_seq, X_win + steps, D); the last entry is the observed layer."""
+        Us = [U] if isinstance(U, np.ndarray) else list(U)
+        n_seq = len(Us)
+        T_u = Us[0].shape[0]
+        assert all(u.shape[0] == T_u for u in Us), 'batched free-run needs equal-length control sequences'
+        steps = T_u - self.U_win
+        con_m = torch.as_tensor(np.stack(Us), dtype=torch.float64, device=self.device).contiguous()
+        con_v, con_rows, con_win, con_dim = None, T_u, self.U_win - 1, self.Du
+        outs = []
+        for L in self.layers:
+            skip = con_win - L.U_win + 1
+            im = iv = None
+            if init_Xs is not None and init_Xs[L.index] is not None and L.X_win > 0:
+                im = torch.as_tensor(np.stack([x[0][-L.X_win:] for x in init_Xs[L.index]]), dtype=torch.float64, device=self.device).contiguous()
+                iv = torch.as_tensor(np.stack([x[1][-L.X_win:] for x in init_Xs[L.index]]), dtype=torch.float64, device=self.device).contiguous()
+            Xm, Xv = self.handle.freerun(n_seq, L.M, L.D, L.X_win, L.U_win, L.U_dim, steps, self.view(L, 'Z'),
+                                         self.view(L, 'variance'), self.view(L, 'inv_l'), self._winv[L.index],
+                                         self._wvec[L.index], im, iv, con_m, con_v, 1e-10, con_rows, skip)
+            outs.append((Xm, Xv))
+            con_m, con_v, con_rows, con_win, con_dim = Xm, Xv, L.X_win + steps, L.X_win, L.D
+        return outs
+
+    # ------------------------------------------------------------------------------------------------------------
     # parity helpers
     # ------------------------------------------------------------------------------------------------------------
     def load_from_oracle(self, om):

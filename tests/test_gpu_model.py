@@ -145,3 +145,25 @@ def test_svi_steps_track_oracle_adam():
     eo = o.elbo_and_grads()[0]
     eg = g.log_likelihood()
     assert abs(eg - eo) <= 1e-8 * abs(eo)
+
+
+@pytest.mark.parametrize('inference', ['svi', None])
+def test_freerun_matches_oracle(inference):
+    """Predictive mean / variance of the moment-matching free-run (layers.py:1551-1571) vs the oracle, all layers."""
+    o, g = build_pair(n_seq=3, T=16, inference=inference, M=6)
+    compare(o, g)                                  # also fills the posteriors (woodbury_inv / woodbury_vector)
+    rng = np.random.default_rng(8)
+    U = rng.standard_normal((30, 2))
+    want = o.freerun(U)
+    got = g.freerun(U)
+    g.handle.sync()
+    for (wm, wv), (gm, gv) in zip(want, got):
+        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
+    # batched: two different control sequences at once give the same as one by one
+    U2 = rng.standard_normal((30, 2))
+    both = g.freerun([U, U2])
+    single = g.freerun(U2)
+    g.handle.sync()
+    np.testing.assert_array_equal(both[-1][0][1].cpu().numpy(), single[-1][0][0].cpu().numpy())
+    np.testing.assert_array_equal(both[-1][0][0].cpu().numpy(), got[-1][0][0].cpu().numpy())
