@@ -46,6 +46,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-update', action='store_true', help='debug: skip the Adam update (kernel ablation runs); INVALID as a benchmark')
     ap.add_argument('--n-total', type=int, default=256, help='sequences in the dataset (config 4: 256)')
     ap.add_argument('--T', type=int, default=4096)
     ap.add_argument('--minibatch', type=int, default=32)
@@ -85,11 +86,12 @@ def main():
     def step(k):
         j = k % n_mb
         return m.svi_step(slice(j * mb_loc, (j + 1) * mb_loc), lr=a.lr, allreduce=allreduce,
-                          qU_ratio=float(mb) / n_total / world if world > 1 else None)
+                          qU_ratio=float(mb) / n_total / world if world > 1 else None, update=not a.no_update)
 
     for k in range(a.warmup):
         step(k)
-    m.handle.sync()
+    if not a.no_update:
+        m.handle.sync()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -104,7 +106,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     psi2_ms, psi2_n, psi2_nmmq = m.handle.get_profile(reset=True)
-    m.handle.sync()
+    if not a.no_update:
+        m.handle.sync()
     elbo = float(e.item())
     tmax = torch.tensor([dt], dtype=torch.float64, device=m.device)
     if world > 1:

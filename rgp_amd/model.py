@@ -426,7 +426,7 @@ class DeepAutoreg(object):
         self._adam = dict(m=torch.zeros_like(self.param_array), v=torch.zeros_like(self.param_array),
                           t_glob=0, t_loc=np.zeros(self.nSeq, dtype=np.int64))
 
-    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None):
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True):
         """One SVI step on the sequences ``seqs`` (slice of contiguous indices or index list): ELBO + gradients,
         optional all-reduce of the global bucket (data-parallel), one Adam update of the global parameters and of the
         touched sequences' latent parameters.  Returns the device ELBO scalar (pre-update)."""
@@ -437,6 +437,8 @@ class DeepAutoreg(object):
         if allreduce is not None:
             allreduce(self.grad_array[:self.n_global + 1])
             elbo = self.grad_array[self.elbo_slot]
+        if not update:              # debugging / kernel ablations only
+            return elbo
         ad['t_glob'] += 1
         G = self.n_global
         h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
