@@ -13,43 +13,98 @@
 #define LOG_2PI 1.8378770664093453
 
 // ---- LDS-resident factorisations (ld = M+1 keeps column accesses conflict free) ---------------------------------
-// left-looking Cholesky, lower, in place; thread i owns row i.
-static __device__ void lds_chol(double* A, int M, int ld, int* status) {
-  const int i = threadIdx.x;
-  for (int j = 0; j < M; ++j) {
-    double s = 0.0;
-    if (i >= j && i < M) {
-      s = A[i * ld + j];
-      for (int k = 0; k < j; ++k) s -= A[i * ld + k] * A[j * ld + k];
-    }
-    __syncthreads();
-    if (i == j) {
-      if (!(s > 0.0)) {
-        if (atomicCAS(&status[0], 0, RGP_ERR_NOT_PD) == 0) status[1] = j;
-      }
-      A[j * ld + j] = sqrt(s);
-    }
-    __syncthreads();
-    if (i > j && i < M) A[i * ld + j] = s / A[j * ld + j];
-    else if (i < j) A[i * ld + j] = 0.0;          // zero the strict upper triangle
-    __syncthreads();
-  }
+// Both run on ONE wave (lanes own rows i = j+lane, j+lane+64): the column recurrences need an ordering point per
+// column, and a 1024-thread s_barrier per column (300 of them per factorisation) cost more than the arithmetic.
+// Inside one wave LDS operations execute in order; the wave-scope fences only stop the compiler from reordering.
+static __device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// in-place inverse of a lower-triangular matrix (LAPACK dtrti2 order, columns last to first); thread i owns row i.
-static __device__ void lds_trtri(double* L, int M, int ld) {
-  const int i = threadIdx.x;
-  for (int j = M - 1; j >= 0; --j) {
-    const double ajj = 1.0 / L[j * ld + j];
-    double tsum = 0.0;
-    if (i > j && i < M) {
-      for (int k = j + 1; k <= i; ++k) tsum += L[i * ld + k] * L[k * ld + j];
+// left-looking Cholesky, lower, in place (M <= 128).
+static __device__ void lds_chol(double* A, int M, int ld, int* status) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int j = 0; j < M; ++j) {
+      double sv[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = j + lane + 64 * r;
+        double s0 = 0.0, s1 = 0.0;
+        if (i < M) {
+          s0 = A[i * ld + j];
+          double s2 = 0.0, s3 = 0.0;
+          int k = 0;
+          for (; k + 7 < j; k += 8) {                          // 16 LDS loads in flight per trip: latency-bound otherwise
+            const double a0 = A[i * ld + k], a1 = A[i * ld + k + 1], a2 = A[i * ld + k + 2], a3 = A[i * ld + k + 3];
+            const double a4 = A[i * ld + k + 4], a5 = A[i * ld + k + 5], a6 = A[i * ld + k + 6], a7 = A[i * ld + k + 7];
+            const double b0 = A[j * ld + k], b1 = A[j * ld + k + 1], b2 = A[j * ld + k + 2], b3 = A[j * ld + k + 3];
+            const double b4 = A[j * ld + k + 4], b5 = A[j * ld + k + 5], b6 = A[j * ld + k + 6], b7 = A[j * ld + k + 7];
+            s0 -= a0 * b0; s1 -= a1 * b1; s2 -= a2 * b2; s3 -= a3 * b3;
+            s0 -= a4 * b4; s1 -= a5 * b5; s2 -= a6 * b6; s3 -= a7 * b7;
+          }
+          for (; k < j; ++k) s0 -= A[i * ld + k] * A[j * ld + k];
+          s0 += s2; s1 += s3;
+        }
+        sv[r] = s0 + s1;
+      }
+      const double piv = __shfl(sv[0], 0);                  // lane 0, r = 0 holds row i = j
+      if (!(piv > 0.0) && lane == 0) {
+        if (atomicCAS(&status[0], 0, RGP_ERR_NOT_PD) == 0) status[1] = j;
+      }
+      const double d = sqrt(piv);
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = j + lane + 64 * r;
+        if (i < M) A[i * ld + j] = (i == j) ? d : sv[r] / d;
+      }
+      for (int i = lane; i < j; i += 64) A[i * ld + j] = 0.0;        // zero the strict upper triangle
+      wave_lds_sync();
     }
-    __syncthreads();
-    if (i > j && i < M) L[i * ld + j] = -ajj * tsum;
-    if (i == j) L[j * ld + j] = ajj;
-    __syncthreads();
   }
+  __syncthreads();
+}
+
+// in-place inverse of a lower-triangular matrix (LAPACK dtrti2 order, columns last to first).
+static __device__ void lds_trtri(double* L, int M, int ld) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int j = M - 1; j >= 0; --j) {
+      const double ajj = 1.0 / L[j * ld + j];
+      double tv[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = j + 1 + lane + 64 * r;
+        double t0 = 0.0, t1 = 0.0;
+        if (i < M) {
+          double t2 = 0.0, t3 = 0.0;
+          int k = j + 1;
+          for (; k + 7 <= i; k += 8) {
+            const double a0 = L[i * ld + k], a1 = L[i * ld + k + 1], a2 = L[i * ld + k + 2], a3 = L[i * ld + k + 3];
+            const double a4 = L[i * ld + k + 4], a5 = L[i * ld + k + 5], a6 = L[i * ld + k + 6], a7 = L[i * ld + k + 7];
+            const double b0 = L[k * ld + j], b1 = L[(k + 1) * ld + j], b2 = L[(k + 2) * ld + j], b3 = L[(k + 3) * ld + j];
+            const double b4 = L[(k + 4) * ld + j], b5 = L[(k + 5) * ld + j], b6 = L[(k + 6) * ld + j], b7 = L[(k + 7) * ld + j];
+            t0 += a0 * b0; t1 += a1 * b1; t2 += a2 * b2; t3 += a3 * b3;
+            t0 += a4 * b4; t1 += a5 * b5; t2 += a6 * b6; t3 += a7 * b7;
+          }
+          for (; k <= i; ++k) t0 += L[i * ld + k] * L[k * ld + j];
+          t0 += t2; t1 += t3;
+        }
+        tv[r] = t0 + t1;
+      }
+      wave_lds_sync();                                       // every lane has read column j before it is overwritten
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = j + 1 + lane + 64 * r;
+        if (i < M) L[i * ld + j] = -ajj * tv[r];
+      }
+      if (lane == 0) L[j * ld + j] = ajj;
+      wave_lds_sync();
+    }
+  }
+  __syncthreads();
 }
 
 static __device__ void copy_in(double* lds, int ld, const double* g, int M) {
@@ -61,44 +116,67 @@ static __device__ void copy_out(double* g, const double* lds, int ld, int M) {
   __syncthreads();
 }
 
-// ---- workgroup GEMM on global (L2-resident) matrices, 4x4 register tiles -----------------------------------------
-// C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C      (row-major, C must not alias A or B)
+// ---- workgroup GEMM, k-panels of 32 staged through LDS, 4x4 register tiles ----------------------------------------
+// C[m x n] = alpha * op(A)[m x k] * op(B)[k x n] + beta * C      (row-major, C must not alias A or B; m, n <= 128)
+// `pan` points at >= 2*GP_K*GP_LD doubles of LDS (the factorisation buffer is reused between factorisations).
+#define GP_K 32
+#define GP_LD 132
 template <bool TA, bool TB>
 static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* __restrict__ A, int lda,
-                               const double* __restrict__ B, int ldb, double beta, double* __restrict__ C, int ldc) {
+                               const double* __restrict__ B, int ldb, double beta, double* __restrict__ C, int ldc,
+                               double* pan) {
+  double* Ap = pan;                    // [GP_K][GP_LD]  Ap[kk][i] = op(A)(i, k0+kk)
+  double* Bp = pan + GP_K * GP_LD;     // [GP_K][GP_LD]  Bp[kk][j] = op(B)(k0+kk, j)
   const int tm = (m + 3) / 4, tn = (n + 3) / 4;
-  for (int tile = threadIdx.x; tile < tm * tn; tile += blockDim.x) {
-    const int i0 = (tile / tn) * 4, j0 = (tile % tn) * 4;
-    double acc[4][4];
+  const int tile = threadIdx.x;
+  const bool has = tile < tm * tn;
+  const int i0 = has ? (tile / tn) * 4 : 0, j0 = has ? (tile % tn) * 4 : 0;
+  double acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int kk = 0; kk < k; ++kk) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int i = i0 + a < m ? i0 + a : m - 1;
-        av[a] = TA ? A[(size_t)kk * lda + i] : A[(size_t)i * lda + kk];
-      }
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = j0 + b < n ? j0 + b : n - 1;
-        bv[b] = TB ? B[(size_t)j * ldb + kk] : B[(size_t)kk * ldb + j];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int k0 = 0; k0 < k; k0 += GP_K) {
+    const int kb = (k - k0 < GP_K) ? k - k0 : GP_K;
+    __syncthreads();
+    for (int e = threadIdx.x; e < GP_K * 128; e += blockDim.x) {
+      int kk, i;
+      if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }      // coalesced along the stored rows
+      double v = 0.0;
+      if (kk < kb && i < m) v = TA ? A[(size_t)(k0 + kk) * lda + i] : A[(size_t)i * lda + k0 + kk];
+      Ap[kk * GP_LD + i] = v;
     }
+    for (int e = threadIdx.x; e < GP_K * 128; e += blockDim.x) {
+      int kk, jx;
+      if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
+      double v = 0.0;
+      if (kk < kb && jx < n) v = TB ? B[(size_t)jx * ldb + k0 + kk] : B[(size_t)(k0 + kk) * ldb + jx];
+      Bp[kk * GP_LD + jx] = v;
+    }
+    __syncthreads();
+    if (has) {
+      for (int kk = 0; kk < kb; ++kk) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = Ap[kk * GP_LD + i0 + a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = Bp[kk * GP_LD + j0 + b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+      }
+    }
+  }
+  if (has) {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int i = i0 + a, j = j0 + b;
-        if (i < m && j < n) {
-          const double c = beta == 0.0 ? 0.0 : beta * C[(size_t)i * ldc + j];
-          C[(size_t)i * ldc + j] = alpha * acc[a][b] + c;
+        const int i = i0 + a, jx = j0 + b;
+        if (i < m && jx < n) {
+          const double c = beta == 0.0 ? 0.0 : beta * C[(size_t)i * ldc + jx];
+          C[(size_t)i * ldc + jx] = alpha * acc[a][b] + c;
         }
       }
   }
@@ -118,7 +196,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
   lds_trtri(lds, M, ld);
   copy_out(c.Linv, lds, ld, M);
   // S = W W^T + a I ; Ls ; LsInv                                  (layers.py:71, svi_vardtc.py:95)
-  wg_gemm<false, true>(M, M, M, 1.0, c.qU_W, M, c.qU_W, M, 0.0, c.S, M);
+  wg_gemm<false, true>(M, M, M, 1.0, c.qU_W, M, c.qU_W, M, 0.0, c.S, M, lds);
   if (t < M) c.S[t * M + t] += c.qU_a[0];
   __syncthreads();
   copy_in(lds, ld, c.S, M);
@@ -128,27 +206,27 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
   lds_trtri(lds, M, ld);
   copy_out(c.LsInv, lds, ld, M);
   // E = Linv Ls ; gmu = Linv mu ; Kinv_mu = Linv^T gmu            (svi_vardtc.py:96-97,153)
-  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.Ls, M, 0.0, c.E, M);
-  wg_gemm<false, false>(M, D, M, 1.0, c.Linv, M, c.qU_m, D, 0.0, c.gmu, D);
-  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.gmu, D, 0.0, c.Kinv_mu, D);
+  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.Ls, M, 0.0, c.E, M, lds);
+  wg_gemm<false, false>(M, D, M, 1.0, c.Linv, M, c.qU_m, D, 0.0, c.gmu, D, lds);
+  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.gmu, D, 0.0, c.Kinv_mu, D, lds);
   // B = D E E^T + gmu gmu^T                                       (:111)
-  wg_gemm<false, true>(M, M, M, 1.0, c.E, M, c.E, M, 0.0, c.EEt, M);
+  wg_gemm<false, true>(M, M, M, 1.0, c.E, M, c.E, M, 0.0, c.EEt, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) c.B[i] = (double)D * c.EEt[i];
   __syncthreads();
-  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.gmu, D, 1.0, c.B, M);
+  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.gmu, D, 1.0, c.B, M, lds);
   // dL_dpsi2 = beta/2 Linv^T (D I - B) Linv                       (:169), symmetric by construction
   for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? (double)D : 0.0) - c.B[i];
   __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M);
-  wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
+  wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
   // dL_dpsi1 = beta Ymean Kinv_mu^T -> coefficient matrix          (:164-167)
   for (int i = t; i < M * D; i += blockDim.x) c.Cpsi1[i] = beta * c.Kinv_mu[i];
   // woodbury_inv = Linv^T (I - E E^T) Linv                        (:154)
   if (c.winv) {
     for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? 1.0 : 0.0) - c.EEt[i];
     __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M);
-    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M);
+    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
+    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
   }
   if (t == 0) {
     c.scal[0] = ldm;      // sum log diag Lm
@@ -158,16 +236,17 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
 
 // ---- stage 2: after the statistics are known --------------------------------------------------------------------
 __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) {
+  extern __shared__ double lds[];
   __shared__ double scratch[16];
   const int M = c.M, D = c.D, t = threadIdx.x;
   const double Dd = (double)D, Nd = (double)c.N;
   const double beta = 1.0 / c.noise[0];
   const double ratio = c.qU_ratio;
   // A = beta Linv psi2 Linv^T                                     (:107)
-  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M);
-  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M, lds);
   // Ybt (M x D) = beta Linv psi1Y^T                               (:98)
-  wg_gemm<false, true>(M, D, M, beta, c.Linv, M, c.psi1Y, M, 0.0, c.Ybt, D);
+  wg_gemm<false, true>(M, D, M, beta, c.Linv, M, c.psi1Y, M, 0.0, c.Ybt, D, lds);
   double sBA = 0.0, trA = 0.0, gY = 0.0, e2 = 0.0, g2 = 0.0;
   for (int i = t; i < M * M; i += blockDim.x) {
     sBA += c.B[i] * c.A[i];
@@ -185,24 +264,24 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   const double dthetaL = -0.5 * Dd * Nd * beta - data_fit * beta;                                   // :139
   const double KL = -0.5 * Dd * M - Dd * c.scal[1] + Dd * c.scal[0] + 0.5 * Dd * e2 + 0.5 * g2;      // :209
   // dL_dKmm = 1/2 (t1 + t1^T) + t3,  t1 = Linv^T B A Linv,  t3 = 1/2 Linv^T (-D A - t2 - t2^T) Linv   (:129-133)
-  wg_gemm<false, false>(M, M, M, 1.0, c.B, M, c.A, M, 0.0, c.T1, M);          // B A
-  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.Ybt, D, 0.0, c.T2, M);       // t2 = gmu Ybar
+  wg_gemm<false, false>(M, M, M, 1.0, c.B, M, c.A, M, 0.0, c.T1, M, lds);          // B A
+  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.Ybt, D, 0.0, c.T2, M, lds);       // t2 = gmu Ybar
   for (int i = t; i < M * M; i += blockDim.x) {
     const int r = i / M, cc = i % M;
     // U = 1/2 (BA + (BA)^T) + 1/2 (-D A - t2 - t2^T): everything that is sandwiched by Linv^T . Linv
     c.T3[i] = 0.5 * (c.T1[i] + c.T1[cc * M + r]) + 0.5 * (-Dd * c.A[i] - c.T2[i] - c.T2[cc * M + r]);
   }
   __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T1, M);
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T1, M, 0.0, c.dKmm, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T1, M, lds);
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T1, M, 0.0, c.dKmm, M, lds);
   // mA = -Linv^T A Linv ; dL_dqU_mean = mA mu + Linv^T Ybt ; dL_dqU_var = D/2 mA      (:145-147)
-  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T1, M);
-  wg_gemm<true, false>(M, M, M, -1.0, c.Linv, M, c.T1, M, 0.0, c.mA, M);
-  wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 0.0, c.gqm, D);
-  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.Ybt, D, 1.0, c.gqm, D);
+  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T1, M, lds);
+  wg_gemm<true, false>(M, M, M, -1.0, c.Linv, M, c.T1, M, 0.0, c.mA, M, lds);
+  wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 0.0, c.gqm, D, lds);
+  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.Ybt, D, 1.0, c.gqm, D, lds);
   // KL gradients (:211-213): Kinv = Linv^T Linv, Sinv = LsInv^T LsInv
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M);
-  wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.T1, M);   // Sinv
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
+  wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.T1, M, lds);   // Sinv
   // Gv = dL_dqU_var - ratio dKL_dvar = D/2 mA - ratio D/2 (Kinv - Sinv)
   for (int i = t; i < M * M; i += blockDim.x) c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.T1[i]);
   for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] -= ratio * c.Kinv_mu[i];
@@ -210,9 +289,9 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   // V = mu mu^T + D S ; dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv
   for (int i = t; i < M * M; i += blockDim.x) c.T2[i] = Dd * c.S[i];
   __syncthreads();
-  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T2, M);
-  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Kinv, M, 0.0, c.T1, M);
-  wg_gemm<false, false>(M, M, M, 1.0, c.Kinv, M, c.T1, M, 0.0, c.T3, M);
+  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T2, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Kinv, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.Kinv, M, c.T1, M, 0.0, c.T3, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) c.dKmm[i] -= ratio * (0.5 * Dd * c.Kinv[i] - 0.5 * c.T3[i]);
   __syncthreads();
   // q(U) parameter gradients (layers.py:173-176)
@@ -220,7 +299,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   if (c.gqU_W) {
     for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.Gv[i] + c.Gv[(i % M) * M + i / M];
     __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.qU_W, M, 0.0, c.gqU_W, M);
+    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.qU_W, M, 0.0, c.gqU_W, M, lds);
   }
   double tr = block_sum((t < M) ? c.Gv[t * M + t] : 0.0, scratch);
   if (t == 0) {
@@ -246,8 +325,9 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
 }
 
 rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c) {
-  if (c.M > 140) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 140 needs the blocked factorisation (not in this build)");
-  const size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
+  size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain LDS attr: ") + hipGetErrorString(e));
   hipLaunchKernelGGL(svi_chain_pre_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
@@ -255,7 +335,10 @@ rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c) {
 }
 
 rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c) {
-  hipLaunchKernelGGL(svi_chain_post_kernel, dim3(1), dim3(CH_THREADS), 0, h->stream, c);
+  const size_t lds = 2 * GP_K * GP_LD * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)svi_chain_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain post LDS attr: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(svi_chain_post_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
   return RGP_OK;
 }
 
@@ -277,8 +360,8 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   lds_trtri(lds, M, ld);
   copy_out(c.Linv, lds, ld, M);
   // A = beta Linv psi2 Linv^T ; Lambda = I + A ; LL = chol(Lambda)          (:120-125)
-  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M);
-  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.A[i] + ((i / M == i % M) ? 1.0 : 0.0);
   __syncthreads();
   copy_in(lds, ld, c.T1, M);
@@ -286,14 +369,14 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   const double ldLL = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
   lds_trtri(lds, M, ld);
   copy_out(c.LLinv, lds, ld, M);
-  wg_gemm<false, false>(M, M, M, 1.0, c.LLinv, M, c.Linv, M, 0.0, c.Li, M);          // Li = L^-1
-  wg_gemm<true, false>(M, M, M, 1.0, c.Li, M, c.Li, M, 0.0, c.G2, M);                // G2 = Li^T Li
-  wg_gemm<false, true>(M, D, M, beta, c.Li, M, c.psi1Y, M, 0.0, c.bT, D);            // b^T (M x D)   (:130)
-  wg_gemm<true, false>(M, D, M, 1.0, c.Li, M, c.bT, D, 0.0, c.vT, D);                // v^T           (:132)
-  wg_gemm<false, true>(M, M, D, 1.0, c.bT, D, c.bT, D, 0.0, c.C, M);                 // C = b^T b     (:133)
+  wg_gemm<false, false>(M, M, M, 1.0, c.LLinv, M, c.Linv, M, 0.0, c.Li, M, lds);          // Li = L^-1
+  wg_gemm<true, false>(M, M, M, 1.0, c.Li, M, c.Li, M, 0.0, c.G2, M, lds);                // G2 = Li^T Li
+  wg_gemm<false, true>(M, D, M, beta, c.Li, M, c.psi1Y, M, 0.0, c.bT, D, lds);            // b^T (M x D)   (:130)
+  wg_gemm<true, false>(M, D, M, 1.0, c.Li, M, c.bT, D, 0.0, c.vT, D, lds);                // v^T           (:132)
+  wg_gemm<false, true>(M, M, D, 1.0, c.bT, D, c.bT, D, 0.0, c.C, M, lds);                 // C = b^T b     (:133)
   if (c.y_uncertain) {
-    wg_gemm<false, false>(M, M, M, 1.0, c.Li, M, c.PsiR, M, 0.0, c.T1, M);
-    wg_gemm<false, true>(M, M, M, beta * beta, c.T1, M, c.Li, M, 1.0, c.C, M);       // + c^T c       (:137-138)
+    wg_gemm<false, false>(M, M, M, 1.0, c.Li, M, c.PsiR, M, 0.0, c.T1, M, lds);
+    wg_gemm<false, true>(M, M, M, beta * beta, c.T1, M, c.Li, M, 1.0, c.C, M, lds);       // + c^T c       (:137-138)
   }
   double trC = 0.0, trA = 0.0, sR = 0.0;
   for (int i = t; i < M; i += blockDim.x) { trC += c.C[i * M + i]; trA += c.A[i * M + i]; }
@@ -301,15 +384,15 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   // R = 1/2 Linv^T [D I - LLinv^T (C + D I) LLinv] Linv
   for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.C[i] + ((i / M == i % M) ? Dd : 0.0);
   __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.LLinv, M, 0.0, c.T2, M);
-  wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.T2, M, 0.0, c.T3, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.LLinv, M, 0.0, c.T2, M, lds);
+  wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.T2, M, 0.0, c.T3, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) c.T3[i] += ((i / M == i % M) ? Dd : 0.0);
   __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T2, M);
-  wg_gemm<true, false>(M, M, M, 0.5, c.Linv, M, c.T2, M, 0.0, c.R, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T2, M, lds);
+  wg_gemm<true, false>(M, M, M, 0.5, c.Linv, M, c.T2, M, 0.0, c.R, M, lds);
   // dL_dKmm = R - D/2 Linv^T A Linv                                                    (:155)
-  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T2, M);
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.T3, M);
+  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T2, M, lds);
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.T3, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) {
     c.dKmm[i] = c.R[i] - 0.5 * Dd * c.T3[i];
     c.dLdpsi2[i] = beta * c.R[i];
@@ -317,11 +400,11 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   }
   sR = block_sum(sR, scratch);
   if (c.winv) {                                                                         // (:161)
-    wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.LLinv, M, 0.0, c.T1, M);
+    wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.LLinv, M, 0.0, c.T1, M, lds);
     for (int i = t; i < M; i += blockDim.x) c.T1[i * M + i] += 1.0;
     __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M);
-    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M);
+    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
+    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
   }
   if (t == 0) {
     const double psi0b = beta * c.psi0sum[0], YRY = beta * c.yry[0];
@@ -344,8 +427,9 @@ void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws) {
 }
 
 rgp_status launch_vardtc_chain(rgp_handle h, const VarDtcChain& c) {
-  if (c.M > 140) return rgp_fail(h, RGP_ERR_BAD_ARG, "vardtc chain: M > 140 needs the blocked factorisation (not in this build)");
-  const size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "vardtc chain: M > 128 needs the blocked factorisation (not in this build)");
+  size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)vardtc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("vardtc chain LDS attr: ") + hipGetErrorString(e));
   hipLaunchKernelGGL(vardtc_chain_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
