@@ -92,6 +92,10 @@ int        rgp_abi_version(void);
 /* Blocks until the handle's stream is idle; returns RGP_ERR_NOT_PD / RGP_ERR_HIP if any step since the last call
  * failed.  pivot (may be NULL) receives the failing Cholesky column. */
 rgp_status rgp_sync_status(rgp_handle h, int* pivot);
+/* rgp_layer_step runs the M x M algebra of a layer on internal side streams so that it overlaps the psi passes of the
+ * next layer; its outputs (gradients of the global parameters, elbo, woodbury_*) are complete on the handle's stream
+ * only after rgp_join (a stream-side wait, no host synchronisation).  rgp_sync_status joins implicitly. */
+rgp_status rgp_join(rgp_handle h);
 /* Upper bound of the workspace (bytes) a layer step of this geometry needs; the workspace grows on demand. */
 int64_t    rgp_workspace_bytes(int64_t N, int M, int Q, int D);
 

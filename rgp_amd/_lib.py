@@ -40,6 +40,7 @@ SYMBOLS = {
     'rgp_last_error': (C.c_char_p, [C.c_void_p]),
     'rgp_abi_version': (C.c_int, []),
     'rgp_sync_status': (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    'rgp_join': (C.c_int, [C.c_void_p]),
     'rgp_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'rgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'rgp_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),

@@ -56,6 +56,10 @@ class Handle(object):
         piv = C.c_int(0)
         self._check(self.lib.rgp_sync_status(self.h, C.byref(piv)))
 
+    def join(self):
+        """Make the handle's stream wait for the side-stream work of the preceding layer steps (no host sync)."""
+        self._check(self.lib.rgp_join(self.h))
+
     def new(self, *shape):
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 

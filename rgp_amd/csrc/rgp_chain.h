@@ -19,8 +19,8 @@ struct SviChain {
 
 size_t svi_chain_ws_doubles(int M, int D);
 void svi_chain_carve(SviChain& c, WsAlloc& ws);
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c);
-rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c);
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t s);
+rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c, hipStream_t s);
 
 // ---- collapsed (Titsias) bound, autoreg/inference/vardtc.py:88-208 ------------------------------------------------
 struct VarDtcChain {

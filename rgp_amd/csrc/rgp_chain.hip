@@ -324,21 +324,21 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1);
 }
 
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c) {
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream) {
   if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
   size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain LDS attr: ") + hipGetErrorString(e));
-  hipLaunchKernelGGL(svi_chain_pre_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
+  hipLaunchKernelGGL(svi_chain_pre_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
   return RGP_OK;
 }
 
-rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c) {
+rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c, hipStream_t stream) {
   const size_t lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain post LDS attr: ") + hipGetErrorString(e));
-  hipLaunchKernelGGL(svi_chain_post_kernel, dim3(1), dim3(CH_THREADS), lds, h->stream, c);
+  hipLaunchKernelGGL(svi_chain_post_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
   return RGP_OK;
 }
 

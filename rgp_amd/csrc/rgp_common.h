@@ -33,9 +33,18 @@ struct rgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  // workspace (grown on demand, never shrunk)
+  // workspace (grown on demand, never shrunk).  Layer steps alternate between two slots so that the M x M chain of one
+  // layer (side streams) can overlap the psi passes of the next layer (main stream).
   char* ws = nullptr;
   size_t ws_bytes = 0;
+  char* ws_slot[2] = {nullptr, nullptr};
+  size_t ws_slot_bytes[2] = {0, 0};
+  int parity = 0;
+  bool overlap = true;
+  hipStream_t side_pre = nullptr, side_post = nullptr;
+  hipEvent_t ev_prep = nullptr, ev_pre = nullptr, ev_stats = nullptr;
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
+  bool done_recorded[2] = {false, false};
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
   int num_cu = 256;
   // optional profiling of the psi2 launch (rgp_set_profiling)
@@ -58,6 +67,8 @@ struct WsAlloc {           // bump allocator over the handle's workspace
 
 rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg);
 rgp_status rgp_ensure_ws(rgp_handle h, size_t bytes);
+rgp_status rgp_ensure_ws_slot(rgp_handle h, int slot, size_t bytes);
+void rgp_join_streams(rgp_handle h);
 
 #define RGP_HIP_CHECK(h, expr)                                                        \
   do {                                                                                \

@@ -1,6 +1,7 @@
 // rgp_layer.hip -- C ABI of librgp_hip.so and the per-layer orchestration (see include/rgp_hip.h).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "rgp_chain.h"
 #include "rgp_psi.h"
@@ -13,7 +14,32 @@ rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg) {
   return code;
 }
 
+void rgp_join_streams(rgp_handle h) {
+  for (int k = 0; k < 2; ++k)
+    if (h->done_recorded[k]) (void)hipStreamWaitEvent(h->stream, h->ev_done[k], 0);
+}
+
+extern "C" rgp_status rgp_join(rgp_handle h) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_join_streams(h);
+  return RGP_OK;
+}
+
+rgp_status rgp_ensure_ws_slot(rgp_handle h, int slot, size_t bytes) {
+  if (bytes <= h->ws_slot_bytes[slot]) return RGP_OK;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->side_pre) (void)hipStreamSynchronize(h->side_pre);
+  if (h->side_post) (void)hipStreamSynchronize(h->side_post);
+  if (h->ws_slot[slot]) (void)hipFree(h->ws_slot[slot]);
+  h->ws_slot[slot] = nullptr; h->ws_slot_bytes[slot] = 0;
+  bytes = bytes + bytes / 8 + (1u << 20);
+  if (hipMalloc((void**)&h->ws_slot[slot], bytes) != hipSuccess) return rgp_fail(h, RGP_ERR_WORKSPACE, "workspace hipMalloc failed");
+  h->ws_slot_bytes[slot] = bytes;
+  return RGP_OK;
+}
+
 rgp_status rgp_ensure_ws(rgp_handle h, size_t bytes) {
+  rgp_join_streams(h);                      // the unit entry points share nothing with in-flight layer steps
   if (bytes <= h->ws_bytes) return RGP_OK;
   if (h->ws) {
     hipStreamSynchronize(h->stream);
@@ -38,6 +64,14 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
+  h->overlap = getenv("RGP_NO_OVERLAP") == nullptr;
+  if (hipStreamCreateWithFlags(&h->side_pre, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_done[0], hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_done[1], hipEventDisableTiming);
   *out = h;
   return RGP_OK;
 }
@@ -46,7 +80,10 @@ extern "C" void rgp_destroy(rgp_handle h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  if (h->side_pre) { hipStreamSynchronize(h->side_pre); hipStreamDestroy(h->side_pre); }
+  if (h->side_post) { hipStreamSynchronize(h->side_post); hipStreamDestroy(h->side_post); }
   if (h->ws) hipFree(h->ws);
+  for (int k = 0; k < 2; ++k) if (h->ws_slot[k]) hipFree(h->ws_slot[k]);
   if (h->status) hipFree(h->status);
   delete h;
 }
@@ -56,6 +93,7 @@ extern "C" const char* rgp_last_error(rgp_handle h) { return h ? h->err.c_str() 
 extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
   if (!h) return RGP_ERR_BAD_ARG;
   int st[2] = {0, 0};
+  rgp_join_streams(h);
   RGP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
   RGP_HIP_CHECK(h, hipMemcpy(st, h->status, sizeof(st), hipMemcpyDeviceToHost));
   if (st[0] != 0) {
@@ -662,8 +700,8 @@ extern "C" rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, doubl
   c.Kj = Kuu_jit; c.noise = noise; c.qU_m = qU_m; c.qU_W = qU_W; c.qU_a = qU_a;
   c.psi0sum = psi0sum; c.psi1Y = psi1Y; c.psi2 = psi2; c.yry = yry;
   c.gqU_m = gqU_m; c.gqU_W = gqU_W; c.gqU_a = gqU_a; c.winv = woodbury_inv; c.status = h->status;
-  if ((st = launch_svi_chain_pre(h, c))) return st;
-  if ((st = launch_svi_chain_post(h, c))) return st;
+  if ((st = launch_svi_chain_pre(h, c, h->stream))) return st;
+  if ((st = launch_svi_chain_post(h, c, h->stream))) return st;
   hipStream_t s = h->stream;
   const size_t mm = (size_t)M * M * sizeof(double), md = (size_t)M * D * sizeof(double);
   if (logL_minus_KL) RGP_HIP_CHECK(h, hipMemcpyAsync(logL_minus_KL, c.bound, sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -805,9 +843,14 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   SviChain c{};
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
   const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, &c);
-  if ((st = rgp_ensure_ws(h, need))) return st;
-  carve_layer(h, h->ws, N, M, Q, D, in->n_seq, L, &c);
+  const int slot = h->parity;
+  h->parity ^= 1;
+  if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
   hipStream_t s = h->stream;
+  // the side-stream work that last used this slot must be finished before the main stream overwrites it
+  if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
+  carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
+  hipStream_t s_pre = h->overlap ? h->side_pre : s, s_post = h->overlap ? h->side_post : s;
   const int QP = L.zt.QP;
 
   // tables + Z terms + rows
@@ -827,10 +870,16 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
   c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv; c.status = h->status;
-  if ((st = launch_svi_chain_pre(h, c))) return st;
+  if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
+  }
+  if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
+  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre, s_pre));
 
   // psi1 side
   launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre, 0));      // Cpsi1 / dL_dpsi2 come from the chain
   {
     const size_t lds = (size_t)M * (D + 1) * sizeof(double);
     int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
@@ -866,19 +915,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
   hipLaunchKernelGGL(psi0_coef_kernel, dim3(1), dim3(64), 0, s, N, D, in->noise, L.psi0coef);
 
-  // data-dependent algebra, kernel-hyperparameter gradients
-  if ((st = launch_svi_chain_post(h, c))) return st;
-  {
-    FinalizeArgs f{};
-    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
-    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
-    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
-    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
-    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
-    launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
-  }
-
-  // latent gradients
+  // latent gradients (main stream; they need only the row gradients and dL/dY)
   int npart = 0;
   if (in->y_uncertain) {
     LatentArgs a{};
@@ -894,10 +931,30 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
     hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
   }
-  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
+  // data-dependent algebra + kernel-hyperparameter gradients on the side stream: overlaps the next layer's psi passes
+  if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre, 0));
+  }
+  if ((st = launch_svi_chain_post(h, c, s_post))) return st;
+  {
+    FinalizeArgs f{};
+    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
+    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
+    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
+    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
+    launch_finalize(s_post, f, L.fin_dlrow, L.fin_gsum);
+  }
+  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s_post, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
                      out->gnoise);
   if (out->woodbury_vector)
-    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.Kinv_mu, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.Kinv_mu, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s_post));
+  if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_done[slot], s_post));
+    h->done_recorded[slot] = true;
+  }
   return last_launch(h, "rgp_layer_step");
 }
 

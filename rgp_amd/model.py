@@ -361,6 +361,7 @@ class DeepAutoreg(object):
                 lout.g_up_mean, lout.g_up_var = self.gmeans.data_ptr(), self.gvars.data_ptr()
             lout.woodbury_inv, lout.woodbury_vector = self._winv[i].data_ptr(), self._wvec[i].data_ptr()
             h.layer_step(lin, lout)
+        h.join()                         # global gradients / ELBO of every layer are produced on the library's side streams
         elbo = self._elbo_buf.sum()
         self.grad_array[self.elbo_slot] = elbo
         self._last_n_batch = n_batch
