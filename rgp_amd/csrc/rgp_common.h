@@ -15,6 +15,13 @@ static __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Broadcast lane `src` (wave-uniform index) of a double to a scalar.
+static __device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 // Sum over the whole workgroup; result valid in every thread. `scratch` holds >= 16 doubles of LDS.
 static __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);

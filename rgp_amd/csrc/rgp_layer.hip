@@ -160,19 +160,32 @@ __global__ void __launch_bounds__(256) svi_rows_kernel(int64_t N, int M, int D, 
   const double beta = 1.0 / noise[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wpb = blockDim.x >> 6;
+  const int m0 = lane < M ? lane : M - 1, m1 = lane + 64 < M ? lane + 64 : M - 1;     // M <= 128: two rows per lane
   for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < N; r += (int64_t)gridDim.x * wpb) {
-    const double* __restrict__ y = Ym + r * D;
-    for (int m = lane; m < M; m += 64) {
-      double acc = 0.0;
-      for (int d = 0; d < D; ++d) acc += y[d] * cs[m * DS + d];
-      dLdpsi1[r * M + m] = acc;
+    // the row's y and psi1 values live in lanes and are broadcast with v_readlane (no serialised scalar loads)
+    double a0 = 0.0, a1 = 0.0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int dn = D - d0 < 64 ? D - d0 : 64;
+      const double yv = lane < dn ? Ym[r * D + d0 + lane] : 0.0;
+      for (int d = 0; d < dn; ++d) {
+        const double yd = readlane_f64(yv, d);
+        a0 += yd * cs[m0 * DS + d0 + d];
+        a1 += yd * cs[m1 * DS + d0 + d];
+      }
     }
+    if (lane < M) dLdpsi1[r * M + lane] = a0;
+    if (lane + 64 < M) dLdpsi1[r * M + lane + 64] = a1;
     if (dYm) {
-      const double* __restrict__ p = psi1 + r * M;
-      for (int d = lane; d < D; d += 64) {
+      const double p0 = lane < M ? psi1[r * M + lane] : 0.0;
+      const double p1 = lane + 64 < M ? psi1[r * M + lane + 64] : 0.0;
+      for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        const int dc = d < D ? d : D - 1;
         double acc = 0.0;
-        for (int m = 0; m < M; ++m) acc += p[m] * cs[m * DS + d];
-        dYm[r * D + d] = -beta * y[d] + acc;
+        const int Ma = M < 64 ? M : 64;
+        for (int m = 0; m < Ma; ++m) acc += readlane_f64(p0, m) * cs[m * DS + dc];
+        for (int m = 64; m < M; ++m) acc += readlane_f64(p1, m - 64) * cs[m * DS + dc];
+        if (d < D) dYm[r * D + d] = -beta * Ym[r * D + d] + acc;
       }
     }
   }
@@ -540,7 +553,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP); L.zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.zt.zd = ws.take<double>((size_t)M * M); L.zt.Kuu = ws.take<double>((size_t)M * M);
   L.rt.N = N; L.rt.QP = QP;
-  L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq);
+  L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq); L.rt.em = ws.take<double>(nq);
   L.rt.g0 = ws.take<double>(N); L.rt.g1 = ws.take<double>(N);
   L.psi1 = ws.take<double>(nm); L.Lp = ws.take<double>(nm);
   L.gmu = ws.take<double>(nq); L.gS = ws.take<double>(nq);

@@ -23,8 +23,9 @@ struct RowTerms {
   double* Xmu;    // [N x QP]  window means minus c, zero padded
   double* d2;     // [N x QP]  1/(2S + l^2) = lam/(1+2 S lam)
   double* e1;     // [N x QP]  1/(S + l^2)
+  double* em;     // [N x QP]  e1 * mu
   double* g0;     // [N]  log(var^2) - 1/2 sum log(1+2 S lam) - sum d2 mu^2       (psi2 row constant)
-  double* g1;     // [N]  log(var)   - 1/2 sum log(1+S lam)                        (psi1 row constant)
+  double* g1;     // [N]  log(var) - 1/2 sum log(1+S lam) - 1/2 sum e1 mu^2         (psi1 row constant, expanded form)
 };
 
 struct WindowSpec {     // implicit lagged windows (rgp_layer_in)

@@ -41,24 +41,28 @@ __global__ void __launch_bounds__(256) prep_z_kernel(int M, int Q, int QP, const
     const int q = i / RGP_PSI2_TEAM, m = i % RGP_PSI2_TEAM;
     ZcT[i] = (q < Q && m < M) ? Z[(size_t)m * Q + q] - c[q] : 0.0;
   }
-  __syncthreads();
-  const double var = variance[0];
-  for (int i = t; i < M * M; i += blockDim.x) {
-    const int a = i / M, b = i % M;
-    double r = 0.0;
-    for (int q = 0; q < Q; ++q) {
-      const double d = Zc[a * QP + q] - Zc[b * QP + q];
-      r += lam[q] * d * d;
-    }
-    zd[i] = -0.25 * r;
-    Kuu[i] = var * exp(-0.5 * r) + (a == b ? jitter : 0.0);
+}
+
+// K_uu + jitter I and the Z-distance table, one workgroup per inducing row.
+__global__ void __launch_bounds__(128) kuu_rows_kernel(int M, int Q, int QP, const double* __restrict__ variance,
+                                                        const double* __restrict__ Zc, const double* __restrict__ lam,
+                                                        double jitter, double* __restrict__ zd, double* __restrict__ Kuu) {
+  const int a = blockIdx.x, b = threadIdx.x;
+  if (b >= M) return;
+  double r = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    const double d = Zc[a * QP + q] - Zc[b * QP + q];
+    r += lam[q] * d * d;
   }
+  zd[a * M + b] = -0.25 * r;
+  Kuu[a * M + b] = variance[0] * exp(-0.5 * r) + (a == b ? jitter : 0.0);
 }
 
 void launch_prep_z(hipStream_t s, int M, int Q, int QP, const double* Z, const double* variance, const double* inv_l,
                    double jitter, const ZTerms& zt) {
   hipLaunchKernelGGL(prep_z_kernel, dim3(1), dim3(256), 0, s, M, Q, QP, Z, variance, inv_l, jitter, zt.c, zt.lam, zt.Zc,
                      zt.ZcT, zt.zd, zt.Kuu);
+  hipLaunchKernelGGL(kuu_rows_kernel, dim3(M), dim3(128), 0, s, M, Q, QP, variance, zt.Zc, zt.lam, jitter, zt.zd, zt.Kuu);
 }
 
 __global__ void row_offsets_kernel(int n_seq, int X_win, const int64_t* __restrict__ own_len, int64_t* row_off) {
@@ -85,7 +89,7 @@ struct RowPrepArgs {
   WindowSpec w;                    // window mode
   const double* variance;
   const double *c, *lam;
-  double *Xmu, *d2, *e1, *g0, *g1;
+  double *Xmu, *d2, *e1, *em, *g0, *g1;
   double *Ym, *Yv, *yry_part;
 };
 
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(256) rowprep_kernel(RowPrepArgs a) {
       if (a.w.U_win > 0) up_base = a.w.up_off[s] + ((a.w.up_len[s] - Ns - a.w.U_win + 1) + nloc) * a.w.U_dim;
     }
     const int Qx = dense ? 0 : a.w.X_win * a.w.X_dim;
-    double sl2 = 0.0, sl1 = 0.0, sdm = 0.0;
+    double sl2 = 0.0, sl1 = 0.0, sdm = 0.0, sem = 0.0;
     for (int q = lane; q < a.QP; q += 64) {
       double mu = 0.0, d2 = 0.0, e1 = 0.0;
       if (q < a.Q) {
@@ -137,15 +141,17 @@ __global__ void __launch_bounds__(256) rowprep_kernel(RowPrepArgs a) {
         sl2 += log(t2);
         sl1 += log(t1);
         sdm += d2 * mu * mu;
+        sem += e1 * mu * mu;
       }
       a.Xmu[r * a.QP + q] = mu;
       a.d2[r * a.QP + q] = d2;
       a.e1[r * a.QP + q] = e1;
+      a.em[r * a.QP + q] = e1 * mu;
     }
-    sl2 = wave_sum(sl2); sl1 = wave_sum(sl1); sdm = wave_sum(sdm);
+    sl2 = wave_sum(sl2); sl1 = wave_sum(sl1); sdm = wave_sum(sdm); sem = wave_sum(sem);
     if (lane == 0) {
       a.g0[r] = 2.0 * logvar - 0.5 * sl2 - sdm;
-      a.g1[r] = logvar - 0.5 * sl1;
+      a.g1[r] = logvar - 0.5 * sl1 - 0.5 * sem;          // includes -1/2 sum e mu^2 (the psi1 exponent is expanded)
     }
     if (!dense && a.Ym) {                              // outputs of this row: own[X_win + n]
       const int64_t ybase = a.w.own_off[s] + (a.w.X_win + nloc) * a.w.D;
@@ -176,7 +182,7 @@ void launch_rowprep_dense(hipStream_t s, int64_t N, int Q, const double* mu, con
                           const ZTerms& zt, const RowTerms& rt) {
   RowPrepArgs a{};
   a.N = N; a.Q = Q; a.QP = zt.QP; a.mu = mu; a.S = S; a.variance = variance; a.c = zt.c; a.lam = zt.lam;
-  a.Xmu = rt.Xmu; a.d2 = rt.d2; a.e1 = rt.e1; a.g0 = rt.g0; a.g1 = rt.g1;
+  a.Xmu = rt.Xmu; a.d2 = rt.d2; a.e1 = rt.e1; a.em = rt.em; a.g0 = rt.g0; a.g1 = rt.g1;
   hipLaunchKernelGGL(rowprep_kernel, dim3(rowprep_blocks(N)), dim3(256), 0, s, a);
 }
 
@@ -185,42 +191,47 @@ void launch_rowprep_window(hipStream_t s, int64_t N, int Q, const WindowSpec& w,
                            const ZTerms& zt, const RowTerms& rt, double* Ym, double* Yv, double* yry_part) {
   RowPrepArgs a{};
   a.N = N; a.Q = Q; a.QP = zt.QP; a.mu = nullptr; a.S = nullptr; a.w = w; a.variance = variance; a.c = zt.c;
-  a.lam = zt.lam; a.Xmu = rt.Xmu; a.d2 = rt.d2; a.e1 = rt.e1; a.g0 = rt.g0; a.g1 = rt.g1;
+  a.lam = zt.lam; a.Xmu = rt.Xmu; a.d2 = rt.d2; a.e1 = rt.e1; a.em = rt.em; a.g0 = rt.g0; a.g1 = rt.g1;
   a.Ym = Ym; a.Yv = Yv; a.yry_part = yry_part;
   hipLaunchKernelGGL(rowprep_kernel, dim3(2048), dim3(256), 0, s, a);   // fixed grid: yry_part has 2048 slots
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// psi1 forward: one wave per row, lanes over m.  Zc staged in LDS with an odd row stride (conflict-free b64 reads).
+// psi1 forward.  psi1[n,m] = exp(g1'[n] - 1/2 sum_q z_mq (e_nq z_mq - 2 (e mu)_nq)),  g1' = g1 - 1/2 sum e mu^2.
+// Thread (m, team): z[m,:] lives in registers; e[n,:] and (e mu)[n,:] are wave-uniform -> SGPR operands (as in psi2).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) psi1_fwd_kernel(int64_t N, int M, int QP, const double* __restrict__ Zc,
-                                                        const double* __restrict__ Xmu, const double* __restrict__ e1,
+template <int QP>
+__global__ void __launch_bounds__(256) psi1_fwd_kernel(const int64_t N, const int M, const double* __restrict__ ZcT,
+                                                        const double* __restrict__ e1, const double* __restrict__ em,
                                                         const double* __restrict__ g1, double* __restrict__ psi1) {
-  extern __shared__ double lds[];
-  const int QS = QP + 1;
-  for (int i = threadIdx.x; i < M * QP; i += blockDim.x) lds[(i / QP) * QS + (i % QP)] = Zc[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wpb = blockDim.x >> 6;
-  for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < N; r += (int64_t)gridDim.x * wpb) {
-    const double* mu = Xmu + r * QP;
-    const double* e = e1 + r * QP;
-    const double g = g1[r];
-    for (int m = lane; m < M; m += 64) {
-      double acc = 0.0;
-      for (int q = 0; q < QP; ++q) {
-        const double d = mu[q] - lds[m * QS + q];
-        acc += e[q] * d * d;
-      }
-      psi1[r * M + m] = exp(g - 0.5 * acc);
+  const int t = threadIdx.x, tr = t & 127;
+  const int team = __builtin_amdgcn_readfirstlane(t >> 7);
+  const bool act = tr < M;
+  double z[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) z[q] = ZcT[q * RGP_PSI2_TEAM + tr];
+  for (int64_t r = (int64_t)blockIdx.x * 2 + team; r < N; r += (int64_t)gridDim.x * 2) {
+    const double* __restrict__ e = e1 + r * QP;
+    const double* __restrict__ m = em + r * QP;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; q += 2) {
+      a0 += z[q] * (e[q] * z[q] - 2.0 * m[q]);
+      a1 += z[q + 1] * (e[q + 1] * z[q + 1] - 2.0 * m[q + 1]);
     }
+    if (act) psi1[r * M + tr] = exp(g1[r] - 0.5 * (a0 + a1));
   }
 }
 
 void launch_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* psi1) {
-  const size_t lds = (size_t)M * (zt.QP + 1) * sizeof(double);
-  const int blocks = rowprep_blocks(N);
-  hipLaunchKernelGGL(psi1_fwd_kernel, dim3(blocks), dim3(256), lds, s, N, M, zt.QP, zt.Zc, rt.Xmu, rt.e1, rt.g1, psi1);
+  int64_t b = (N + 1) / 2;
+  const int blocks = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  switch (zt.QP) {
+#define P1F(qp) case qp: hipLaunchKernelGGL((psi1_fwd_kernel<qp>), dim3(blocks), dim3(256), 0, s, N, M, zt.ZcT, rt.e1, rt.em, rt.g1, psi1); break;
+    P1F(8) P1F(16) P1F(24) P1F(32) P1F(40) P1F(48) P1F(56) P1F(64)
+#undef P1F
+    default: break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
