@@ -563,9 +563,9 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
   L.dz2_part = ws.take<double>((size_t)2 * L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.dlam1_part = ws.take<double>((size_t)L.nblk1 * QP); L.dlam1 = ws.take<double>(QP);
-  L.dlam2_part = ws.take<double>((size_t)L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
+  L.dlam2_part = ws.take<double>((size_t)2 * L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
   L.lsum1_part = ws.take<double>(L.nblk1); L.lsum1 = ws.take<double>(1);
-  L.wsum2_part = ws.take<double>(L.nblk2); L.wsum2 = ws.take<double>(1);
+  L.wsum2_part = ws.take<double>((size_t)2 * L.nblk2); L.wsum2 = ws.take<double>(1);
   L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
   L.psi1Y_part = ws.take<double>((size_t)L.nblk1 * (D > 0 ? D : 1) * M); L.psi1Y = ws.take<double>((size_t)(D > 0 ? D : 1) * M);
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
@@ -678,8 +678,8 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
     launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   FinalizeArgs f{};
   f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = variance;
@@ -803,8 +803,8 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
     if ((st = launch_psi2(h, false, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
     launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   {
     FinalizeArgs f{};
@@ -922,8 +922,8 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
     launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
   hipLaunchKernelGGL(psi0_coef_kernel, dim3(1), dim3(64), 0, s, N, D, in->noise, L.psi0coef);

@@ -413,8 +413,45 @@ static __device__ __forceinline__ void psi2_pair(const double* __restrict__ zs, 
   }
 }
 
-// Every pointer is a separate noalias kernel argument: that is what lets the compiler prove the wave-uniform loads
-// of z[m',:], d2[n,:] and mu[n,:] are not clobbered by the kernel's own stores and turn them into scalar loads.
+// Sweep m' over [a, b) for the thread's row: Gram + exp (+ forward accumulation, + y update).
+// dLs[m', m] stream: two loads in flight (prefetch distance 2), consumed in registers without rotation copies.
+template <int QP, bool FWD, bool BWD>
+static __device__ __forceinline__ void psi2_sweep(const int a, const int b, const double* __restrict__ Zc,
+                                                  const double* __restrict__ dlrow, const int M, const double (&dzl)[QP],
+                                                  double (&y)[QP], double& v, const double base,
+                                                  const double* __restrict__ hb, double* __restrict__ p2acc, const int tri,
+                                                  const int tr, const bool act) {
+  if (a >= b) return;
+  const int last = b - 1;
+  double dlA = BWD ? dlrow[(size_t)a * M] : 0.0;
+  double dlB = BWD ? dlrow[(size_t)((a + 1 < b) ? a + 1 : last) * M] : 0.0;
+  for (int mp = a; mp < b; mp += 2) {
+    const int mpa = mp, mpb = (mp + 1 < b) ? mp + 1 : last;
+    const double dla = dlA, dlb = dlB;
+    if (BWD) {
+      dlA = dlrow[(size_t)((mp + 2 < b) ? mp + 2 : last) * M];
+      dlB = dlrow[(size_t)((mp + 3 < b) ? mp + 3 : last) * M];
+    }
+    {
+      const bool own = act && mpa >= tr;
+      psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpa * QP, dzl, y, v, base, hb[mpa], dla,
+                              p2acc + (own ? mpa * (mpa + 1) / 2 + tr : tri + tr));
+    }
+    if (mp + 1 < b) {
+      const bool own = act && mpb >= tr;
+      psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpb * QP, dzl, y, v, base, hb[mpb], dlb,
+                              p2acc + (own ? mpb * (mpb + 1) / 2 + tr : tri + tr));
+    }
+  }
+}
+
+// Workgroup = two TEAMS of 128 threads; team k works on data row r0 + 2*it + k and sweeps ALL m' for its inducing row, so
+// y_n[m,:] is complete in one thread and the dZ slab is read-modified-written once per (row, m) -- half the L2 traffic of
+// splitting the m' sweep between the teams.  Both teams accumulate psi2n into the shared packed M x M LDS array; to keep
+// that deterministic the sweep runs in two phases separated by a barrier: team 0 does m' in [0, M/2) while team 1 does
+// [M/2, M), then they swap, so every LDS slot receives team 0's add (of its row) strictly before / after team 1's.
+// Every pointer is a separate noalias kernel argument: that is what lets the compiler prove the wave-uniform loads of
+// z[m',:], d2[n,:] and mu[n,:] are not clobbered by the kernel's own stores and turn them into scalar loads.
 // Occupancy: 2 workgroups (8 waves) per CU = 2 waves per SIMD; measured v_fma_f64 throughput is 31 TF at 1 wave/SIMD
 // and 63.5 TF at 2 (profiles/r1_f64_peak.txt), so the register budget is capped at 256 by __launch_bounds__.
 template <int QP, bool FWD, bool BWD>
@@ -428,25 +465,25 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
   extern __shared__ double lds[];
   const int tri = M * (M + 1) / 2;
   double* p2acc = lds;                                   // [tri + 128] (+128 dummy slots)   (FWD)
-  double* hbuf = lds + (FWD ? tri + RGP_PSI2_TEAM : 0);  // [128]
-  double* red = hbuf + RGP_PSI2_TEAM;                    // [4 waves x RED_WAVE]          (BWD)
+  double* hbuf = lds + (FWD ? tri + RGP_PSI2_TEAM : 0);  // [2 teams x 128]
+  double* red = hbuf + 2 * RGP_PSI2_TEAM;                // [4 waves x RED_WAVE]          (BWD)
   double* res = red + (BWD ? 4 * RED_WAVE : 0);          // [4 waves x (2*QP + 8)]        (BWD)
 
   const int t = threadIdx.x;
   const int tr = t & (RGP_PSI2_TEAM - 1);                // inducing row owned by this thread
-  const int half = __builtin_amdgcn_readfirstlane(t >> 7);   // which half of the m' sweep (wave-uniform: keeps z[m'] in SGPRs)
+  const int team = __builtin_amdgcn_readfirstlane(t >> 7);   // wave-uniform: keeps z[m'] and the row operands in SGPRs
   const bool act = tr < M;
   const int tm = act ? tr : M - 1;
   const int Mh = (M + 1) >> 1;
-  const int mp0 = half ? Mh : 0, mp1 = half ? M : Mh;
-  const double* __restrict__ zrowp = Zc + (size_t)tm * QP;   // (a transposed, coalesced copy ZcT was measured slower: 17.0 vs 12.7 ms)
+  const double* __restrict__ zrowp = Zc + (size_t)tm * QP;
 #define zrow(q) zrowp[q]
+  double* hb = hbuf + team * RGP_PSI2_TEAM;
 
   if (FWD) {
     for (int i = t; i < tri + RGP_PSI2_TEAM; i += PSI2_THREADS) p2acc[i] = 0.0;
   }
-  // dZ partial of this (block, half): layout [q][row]
-  double* dzp = BWD ? dz_part + ((size_t)blockIdx.x * 2 + half) * QP * RGP_PSI2_TEAM : nullptr;
+  // dZ partial of this (block, team): layout [q][row]
+  double* dzp = BWD ? dz_part + ((size_t)blockIdx.x * 2 + team) * QP * RGP_PSI2_TEAM : nullptr;
   double ellq = 0.0;                                     // 1/4 sum_q lam_q z_mq^2
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
@@ -456,13 +493,15 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
   double dlam_acc = 0.0, wsum_acc = 0.0;
   __syncthreads();
 
-  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + 1) / 2 * 2;       // even: the teams take alternate rows
   const int64_t r0 = (int64_t)blockIdx.x * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
   const double* __restrict__ dlrow = dLs_g + tm;          // dLs[m'][m]: coalesced over the lanes' rows
 
-  for (int64_t n = r0; n < r1; ++n) {
+  for (int64_t rr = r0; rr < r1; rr += 2) {
     asm volatile("" ::: "memory");                          // keep the per-row reloads of z[m,:] out of the registers
+    const bool valid = rr + team < r1;
+    const int64_t n = valid ? rr + team : r1 - 1;
     const double* __restrict__ dn = d2_g + n * QP;          // wave-uniform -> scalar loads
     const double* __restrict__ mun = Xmu_g + n * QP;
     double dzl[QP];
@@ -476,8 +515,8 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
       h1 += z1 * dn[q + 1] * (mun[q + 1] - 0.25 * z1);
     }
     const double h = (h0 + h1) - ellq;
-    if (half == 0) hbuf[tr] = h;
-    const double base = act ? (g0_g[n] + h) : -INFINITY;    // exp(-inf) = 0: padded lanes contribute nothing
+    hb[tr] = h;
+    const double base = (act && valid) ? (g0_g[n] + h) : -INFINITY;    // exp(-inf) = 0: padded lanes / rows add nothing
     __syncthreads();
 
     double y[QP];
@@ -486,44 +525,26 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
 #pragma unroll
       for (int q = 0; q < QP; ++q) y[q] = 0.0;
     }
-    // dLs[m', m] stream: two loads in flight (prefetch distance 2), consumed in registers without rotation copies
-    const int last = mp1 - 1;
-    double dlA = BWD ? dlrow[(size_t)mp0 * M] : 0.0;
-    double dlB = BWD ? dlrow[(size_t)((mp0 + 1 < mp1) ? mp0 + 1 : last) * M] : 0.0;
-    for (int mp = mp0; mp < mp1; mp += 2) {
-      const int mpa = mp, mpb = (mp + 1 < mp1) ? mp + 1 : last;
-      const double dla = dlA, dlb = dlB;
-      if (BWD) {
-        dlA = dlrow[(size_t)((mp + 2 < mp1) ? mp + 2 : last) * M];
-        dlB = dlrow[(size_t)((mp + 3 < mp1) ? mp + 3 : last) * M];
-      }
-      {
-        const bool own = act && mpa >= tr;
-        psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpa * QP, dzl, y, v, base, hbuf[mpa], dla,
-                                p2acc + (own ? mpa * (mpa + 1) / 2 + tr : tri + tr));
-      }
-      if (mp + 1 < mp1) {
-        const bool own = act && mpb >= tr;
-        psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpb * QP, dzl, y, v, base, hbuf[mpb], dlb,
-                                p2acc + (own ? mpb * (mpb + 1) / 2 + tr : tri + tr));
-      }
-    }
+    // phase 1: team 0 sweeps [0, Mh), team 1 sweeps [Mh, M);  phase 2: swapped
+    psi2_sweep<QP, FWD, BWD>(team ? Mh : 0, team ? M : Mh, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
+    if (FWD) __syncthreads();
+    psi2_sweep<QP, FWD, BWD>(team ? 0 : Mh, team ? Mh : M, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
 
     if (BWD) {
       asm volatile("" ::: "memory");
-      // dZ partial:  d (v (2 mu - z) - y)      (linear in v and y, so each half adds its own share)
+      // dZ partial:  d (v (2 mu - z) - y)
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
         const double z = zrow(q);
         dzp[q * RGP_PSI2_TEAM + tr] += dn[q] * (v * (2.0 * mun[q] - z) - y[q]);
       }
-      // a1[q] = sum_m v z ; a23[q] = 1/2 sum_m z (v z + y) ; w = sum_m v   (sums over both halves and all rows).
+      // a1[q] = sum_m v z ; a23[q] = 1/2 sum_m z (v z + y) ; w = sum_m v   (sums over the team's 128 rows).
       // Each wave reduces its 64 lanes through its own LDS region (in-order LDS, no workgroup barrier), then one barrier
-      // and a 4-term sum per value.
+      // and a 2-term sum per value.
+      const int wave = t >> 6, lane = t & 63;
+      double* wres = res + wave * (2 * QP + 8);
       {
-        const int wave = t >> 6, lane = t & 63;
         double* wred = red + wave * RED_WAVE;
-        double* wres = res + wave * (2 * QP + 8);
         const double ws = wave_sum(v);
         if (lane == 0) wres[2 * QP] = ws;
         for (int q0 = 0; q0 < QP; q0 += RED_QC) {
@@ -551,12 +572,13 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
       }
       __syncthreads();
       const int RW = 2 * QP + 8;
-      const double w = (res[2 * QP] + res[RW + 2 * QP]) + (res[2 * RW + 2 * QP] + res[3 * RW + 2 * QP]);
-      if (t < Q) {
-        const int q = t;
+      const double* tres = res + (2 * team) * RW;            // the team's two waves
+      const double w = tres[2 * QP] + tres[RW + 2 * QP];
+      if (tr < Q && valid) {
+        const int q = tr;
         const double mu = mun[q], dq = dn[q];
-        const double a1 = (res[q] + res[RW + q]) + (res[2 * RW + q] + res[3 * RW + q]);
-        const double a23 = (res[QP + q] + res[RW + QP + q]) + (res[2 * RW + QP + q] + res[3 * RW + QP + q]);
+        const double a1 = tres[q] + tres[RW + q];
+        const double a23 = tres[QP + q] + tres[RW + QP + q];
         const double dmu = 2.0 * dq * (a1 - mu * w);
         const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
         const double dS = -2.0 * dq * dq * dd;
@@ -569,11 +591,11 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
         }
         const double il = 1.0 / lam_g[q];
         dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
-      } else if (t >= Q && t < QP && !accumulate) {
-        gmu_g[n * QP + t] = 0.0;
-        gS_g[n * QP + t] = 0.0;
+      } else if (tr >= Q && tr < QP && valid && !accumulate) {
+        gmu_g[n * QP + tr] = 0.0;
+        gS_g[n * QP + tr] = 0.0;
       }
-      if (t == 0) wsum_acc += w;
+      if (tr == 0 && valid) wsum_acc += w;
       __syncthreads();
     } else {
       __syncthreads();      // hbuf is rewritten at the top of the next iteration
@@ -586,23 +608,23 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
     for (int i = t; i < tri; i += PSI2_THREADS) out[i] = p2acc[i];
   }
   if (BWD) {
-    if (t < QP) dlam_part[(size_t)blockIdx.x * QP + t] = (t < Q) ? dlam_acc : 0.0;
-    if (t == 0) wsum_part[blockIdx.x] = wsum_acc;
+    if (tr < QP) dlam_part[((size_t)blockIdx.x * 2 + team) * QP + tr] = (tr < Q) ? dlam_acc : 0.0;
+    if (tr == 0) wsum_part[(size_t)blockIdx.x * 2 + team] = wsum_acc;
   }
 }
+#undef zrow
 
 size_t psi2_num_blocks(rgp_handle h, int64_t N) {
   // two 256-thread workgroups per CU (LDS holds one packed M x M accumulator each; 2 waves per SIMD)
   int64_t b = 2 * (int64_t)h->num_cu;
-  if (b > N) b = N;
+  if (b > (N + 1) / 2) b = (N + 1) / 2;
   return (size_t)(b < 1 ? 1 : b);
 }
-#undef zrow
 
 template <int QP>
 static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Args& a, int nblk) {
   const int tri = a.M * (a.M + 1) / 2;
-  size_t lds = (size_t)RGP_PSI2_TEAM;
+  size_t lds = (size_t)2 * RGP_PSI2_TEAM;
   if (fwd) lds += tri + RGP_PSI2_TEAM;
   if (bwd) lds += 4 * RED_WAVE + 4 * (2 * QP + 8);
   lds *= sizeof(double);
