@@ -673,13 +673,14 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
     Psi2Out o{};
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
-    if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
+    const Psi2Plan pl = psi2_plan(h, N, M, QP, true, true);
+    if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid))) return st;
     const int tri = M * (M + 1) / 2;
-    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_reduce(s, pl.n_p2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
-    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    launch_reduce(s, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   FinalizeArgs f{};
   f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = variance;
@@ -801,10 +802,11 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     Psi2Out o{};
     o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
-    if ((st = launch_psi2(h, false, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2))) return st;
-    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    const Psi2Plan pl = psi2_plan(h, N, M, QP, false, true);
+    if ((st = launch_psi2(h, false, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid))) return st;
+    launch_reduce(s, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   {
     FinalizeArgs f{};
@@ -915,15 +917,16 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
     prof_begin(h, (double)N * M * M * Q);
-    st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, L.nblk2);
+    const Psi2Plan pl = psi2_plan(h, N, M, QP, true, true);
+    st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid);
     prof_end(h);
     if (st) return st;
     const int tri = M * (M + 1) / 2;
-    launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    launch_reduce(s, pl.n_p2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
-    launch_reduce(s, 2 * L.nblk2, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, 2 * L.nblk2, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    launch_reduce(s, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
+    launch_reduce(s, pl.n_dl, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
   hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
   hipLaunchKernelGGL(psi0_coef_kernel, dim3(1), dim3(64), 0, s, N, D, in->noise, L.psi0coef);

@@ -37,6 +37,10 @@ struct WindowSpec {     // implicit lagged windows (rgp_layer_in)
 };
 
 size_t psi2_num_blocks(rgp_handle h, int64_t N);
+bool psi2_use_rows4(int M, int QP);
+// grid size and number of per-workgroup partial slabs each psi2 launch produces
+struct Psi2Plan { int grid, n_p2, n_dz, n_dl; };
+Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd);      // fused pass with four teams per workgroup and the dZ accumulator in LDS
 
 void launch_prep_z(hipStream_t s, int M, int Q, int QP, const double* Z, const double* variance, const double* inv_l,
                    double jitter, const ZTerms& zt);

@@ -614,6 +614,198 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
 }
 #undef zrow
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused forward + backward pass, FOUR teams (512 threads, one workgroup per CU), used when its LDS image fits 160 KB
+// (M = 100, Q = 40: 129 KB).  Same arithmetic as psi2_rows_kernel<QP, true, true>, but the dZ accumulator ([QP][128])
+// lives in LDS next to the packed M x M forward accumulator instead of an L2 slab: the slab version moved 8-11 GB of
+// HBM/fabric traffic per launch (profiles/r1_psi2_traffic_raw.json) for 0.2 GB of algorithmic bytes.
+// Team k works on data row rr + k.  Shared accumulators stay deterministic by rotation: in sweep phase ph team k handles
+// the m' quarter (k + ph) % 4, and in dZ phase ph it adds the q quarter (k + ph) % 4 -- within a phase the teams touch
+// disjoint LDS slots, and every slot is updated by teams in phase order.
+// ------------------------------------------------------------------------------------------------------------------
+#define PSI2_T4 512
+template <int QP>
+__global__ void __launch_bounds__(PSI2_T4, 2)
+psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __restrict__ Zc, const double* __restrict__ lam_g,
+                  const double* __restrict__ dLs_g, const double* __restrict__ Xmu_g, const double* __restrict__ d2_g,
+                  const double* __restrict__ g0_g, double* __restrict__ p2_part, double* __restrict__ dz_part,
+                  double* __restrict__ dlam_part, double* __restrict__ wsum_part, double* __restrict__ gmu_g,
+                  double* __restrict__ gS_g, const int accumulate) {
+  extern __shared__ double lds[];
+  const int tri = M * (M + 1) / 2;
+  double* p2acc = lds;                                   // [tri + 128] (+128 dummy slots)
+  double* dzacc = p2acc + tri + RGP_PSI2_TEAM;           // [QP x 128]
+  double* hbuf = dzacc + QP * RGP_PSI2_TEAM;             // [4 teams x 128]
+  double* red = hbuf + 4 * RGP_PSI2_TEAM;                // [8 waves x RED_WAVE]
+  double* res = red + 8 * RED_WAVE;                      // [8 waves x (2*QP + 8)]
+
+  const int t = threadIdx.x;
+  const int tr = t & (RGP_PSI2_TEAM - 1);
+  const int team = __builtin_amdgcn_readfirstlane(t >> 7);     // 0..3, wave-uniform
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  const int Mq = (M + 3) >> 2;
+  const double* __restrict__ zrowp = Zc + (size_t)tm * QP;
+#define zrow(q) zrowp[q]
+  double* hb = hbuf + team * RGP_PSI2_TEAM;
+
+  for (int i = t; i < tri + RGP_PSI2_TEAM + QP * RGP_PSI2_TEAM; i += PSI2_T4) p2acc[i] = 0.0;     // p2acc and dzacc are adjacent
+  double ellq = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) ellq += 0.25 * lam_g[q] * zrow(q) * zrow(q);
+  double dlam_acc = 0.0, wsum_acc = 0.0;
+  __syncthreads();
+
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + 3) / 4 * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  const double* __restrict__ dlrow = dLs_g + tm;
+
+  for (int64_t rr = r0; rr < r1; rr += 4) {
+    asm volatile("" ::: "memory");
+    const bool valid = rr + team < r1;
+    const int64_t n = valid ? rr + team : r1 - 1;
+    const double* __restrict__ dn = d2_g + n * QP;
+    const double* __restrict__ mun = Xmu_g + n * QP;
+    double dzl[QP];
+    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; q += 2) {
+      const double z0 = zrow(q), z1 = zrow(q + 1);
+      dzl[q] = z0 * (dn[q] - lam_g[q]);
+      dzl[q + 1] = z1 * (dn[q + 1] - lam_g[q + 1]);
+      h0 += z0 * dn[q] * (mun[q] - 0.25 * z0);
+      h1 += z1 * dn[q + 1] * (mun[q + 1] - 0.25 * z1);
+    }
+    const double h = (h0 + h1) - ellq;
+    hb[tr] = h;
+    const double base = (act && valid) ? (g0_g[n] + h) : -INFINITY;
+    __syncthreads();
+
+    double y[QP];
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = 0.0;
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+      const int rq = (team + ph) & 3;
+      const int a = rq * Mq, b = (a + Mq < M) ? a + Mq : M;
+      psi2_sweep<QP, true, true>(a, b, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
+      if (ph < 3) __syncthreads();
+    }
+
+    asm volatile("" ::: "memory");
+    // per-team reductions (two waves each) through per-wave LDS regions
+    const int wave = t >> 6, lane = t & 63;
+    double* wres = res + wave * (2 * QP + 8);
+    {
+      double* wred = red + wave * RED_WAVE;
+      const double ws = wave_sum(v);
+      if (lane == 0) wres[2 * QP] = ws;
+      for (int q0 = 0; q0 < QP; q0 += RED_QC) {
+#pragma unroll
+        for (int j = 0; j < RED_QC; ++j) {
+          const double z = zrow(q0 + j);
+          wred[j * RED_RS + lane] = v * z;
+          wred[(RED_QC + j) * RED_RS + lane] = 0.5 * z * (v * z + y[q0 + j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int jv = lane >> 3, part = lane & 7;
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += wred[jv * RED_RS + part + 8 * k];
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        sacc += __shfl_xor(sacc, 4);
+        if (part == 0) wres[(jv < RED_QC ? 0 : QP) + q0 + (jv % RED_QC)] = sacc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab, q quarters rotated over the teams
+    constexpr int QQ = QP / 4;                           // QP is a multiple of 8
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+      const int rq = (team + ph) & 3;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (rq == k) {
+#pragma unroll
+          for (int j = 0; j < QQ; ++j) {
+            const int q = k * QQ + j;
+            dzacc[q * RGP_PSI2_TEAM + tr] += dn[q] * (v * (2.0 * mun[q] - zrow(q)) - y[q]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int RW = 2 * QP + 8;
+    const double* tres = res + (2 * team) * RW;
+    const double w = tres[2 * QP] + tres[RW + 2 * QP];
+    if (tr < Q && valid) {
+      const int q = tr;
+      const double mu = mun[q], dq = dn[q];
+      const double a1 = tres[q] + tres[RW + q];
+      const double a23 = tres[QP + q] + tres[RW + QP + q];
+      const double dmu = 2.0 * dq * (a1 - mu * w);
+      const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
+      const double dS = -2.0 * dq * dq * dd;
+      if (accumulate) {
+        gmu_g[n * QP + q] += dmu;
+        gS_g[n * QP + q] += dS;
+      } else {
+        gmu_g[n * QP + q] = dmu;
+        gS_g[n * QP + q] = dS;
+      }
+      const double il = 1.0 / lam_g[q];
+      dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
+    } else if (tr >= Q && tr < QP && valid && !accumulate) {
+      gmu_g[n * QP + tr] = 0.0;
+      gS_g[n * QP + tr] = 0.0;
+    }
+    if (tr == 0 && valid) wsum_acc += w;
+    __syncthreads();
+  }
+
+  {
+    double* out = p2_part + (size_t)blockIdx.x * tri;
+    for (int i = t; i < tri; i += PSI2_T4) out[i] = p2acc[i];
+    double* outz = dz_part + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM;
+    for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) outz[i] = dzacc[i];
+  }
+  if (tr < QP) dlam_part[((size_t)blockIdx.x * 4 + team) * QP + tr] = (tr < Q) ? dlam_acc : 0.0;
+  if (tr == 0) wsum_part[(size_t)blockIdx.x * 4 + team] = wsum_acc;
+}
+#undef zrow
+
+// LDS bytes of the four-team kernel
+static size_t psi2_rows4_lds(int M, int QP) {
+  const size_t tri = (size_t)M * (M + 1) / 2;
+  return (tri + RGP_PSI2_TEAM + (size_t)QP * RGP_PSI2_TEAM + 4 * RGP_PSI2_TEAM + 8 * RED_WAVE + 8 * (2 * (size_t)QP + 8)) * sizeof(double);
+}
+
+bool psi2_use_rows4(int M, int QP) {
+  static const bool off = getenv("RGP_PSI2_NO_ROWS4") != nullptr;
+  return !off && psi2_rows4_lds(M, QP) <= 160 * 1024;
+}
+
+Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
+  Psi2Plan pl;
+  if (fwd && bwd && psi2_use_rows4(M, QP)) {
+    int64_t g = h->num_cu;                         // one 512-thread workgroup per CU
+    if (g > (N + 3) / 4) g = (N + 3) / 4;
+    pl.grid = (int)(g < 1 ? 1 : g);
+    pl.n_p2 = pl.grid; pl.n_dz = pl.grid; pl.n_dl = 4 * pl.grid;
+  } else {
+    pl.grid = (int)psi2_num_blocks(h, N);
+    pl.n_p2 = pl.grid; pl.n_dz = 2 * pl.grid; pl.n_dl = 2 * pl.grid;
+  }
+  return pl;
+}
+
 size_t psi2_num_blocks(rgp_handle h, int64_t N) {
   // two 256-thread workgroups per CU (LDS holds one packed M x M accumulator each; 2 waves per SIMD)
   int64_t b = 2 * (int64_t)h->num_cu;
@@ -637,6 +829,14 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
                        a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part,        \
                        a.o.gmu, a.o.gS, a.o.accumulate);                                                              \
   } while (0)
+  if (fwd && bwd && psi2_use_rows4(a.M, QP)) {
+    const size_t l4 = psi2_rows4_lds(a.M, QP);
+    hipError_t e = hipFuncSetAttribute((const void*)psi2_rows4_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((psi2_rows4_kernel<QP>), dim3(nblk), dim3(PSI2_T4), l4, s, a.N, a.M, a.Q, a.Zc, a.lam, a.dLs, a.Xmu, a.d2,
+                       a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS, a.o.accumulate);
+    return hipSuccess;
+  }
   if (fwd && bwd) PSI2_LAUNCH(true, true);
   else if (fwd) PSI2_LAUNCH(true, false);
   else PSI2_LAUNCH(false, true);
