@@ -127,10 +127,12 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
                                double* pan) {
   double* Ap = pan;                    // [GP_K][GP_LD]  Ap[kk][i] = op(A)(i, k0+kk)
   double* Bp = pan + GP_K * GP_LD;     // [GP_K][GP_LD]  Bp[kk][j] = op(B)(k0+kk, j)
-  const int tm = (m + 3) / 4, tn = (n + 3) / 4;
-  const int tile = threadIdx.x;
-  const bool has = tile < tm * tn;
-  const int i0 = has ? (tile / tn) * 4 : 0, j0 = has ? (tile % tn) * 4 : 0;
+  // thread (ig, jl): rows 4 ig .. 4 ig + 3, columns jl, jl+32, jl+64, jl+96.  The column interleave makes the Bp reads of a
+  // 32-lane group hit consecutive banks (a 4-contiguous-column tile gives a 4-way ds_read_b64 conflict), the Ap reads are
+  // broadcasts.
+  const int ig = threadIdx.x >> 5, jl = threadIdx.x & 31;
+  const int i0 = 4 * ig;
+  const bool has = i0 < m && jl < n;
   double acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -155,12 +157,13 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
     }
     __syncthreads();
     if (has) {
+#pragma unroll 4
       for (int kk = 0; kk < kb; ++kk) {
         double av[4], bv[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) av[a] = Ap[kk * GP_LD + i0 + a];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bv[b] = Bp[kk * GP_LD + j0 + b];
+        for (int b = 0; b < 4; ++b) bv[b] = Bp[kk * GP_LD + jl + 32 * b];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -173,7 +176,7 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int i = i0 + a, jx = j0 + b;
+        const int i = i0 + a, jx = jl + 32 * b;
         if (i < m && jx < n) {
           const double c = beta == 0.0 ? 0.0 : beta * C[(size_t)i * ldc + jx];
           C[(size_t)i * ldc + jx] = alpha * acc[a][b] + c;
