@@ -96,6 +96,11 @@ rgp_status rgp_sync_status(rgp_handle h, int* pivot);
  * next layer; its outputs (gradients of the global parameters, elbo, woodbury_*) are complete on the handle's stream
  * only after rgp_join (a stream-side wait, no host synchronisation).  rgp_sync_status joins implicitly. */
 rgp_status rgp_join(rgp_handle h);
+/* Optional: start the data-independent part of a layer (K_uu, its factorisation and everything of the SVI bound that
+ * needs only the parameters) early on a side stream.  Call it for the layers of a step in the order in which
+ * rgp_layer_step will be called; each rgp_layer_step then consumes the oldest prepared layer (same geometry and
+ * parameter pointers).  Up to 3 layers may be outstanding.  No-op for RGP_MODE_VARDTC. */
+rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in);
 /* Upper bound of the workspace (bytes) a layer step of this geometry needs; the workspace grows on demand. */
 int64_t    rgp_workspace_bytes(int64_t N, int M, int Q, int D);
 

@@ -44,6 +44,7 @@ SYMBOLS = {
     'rgp_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'rgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'rgp_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    'rgp_layer_prepare': (C.c_int, [C.c_void_p, C.POINTER(LayerIn)]),
     'rgp_layer_step': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), C.POINTER(LayerOut)]),
     'rgp_kuu': (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_double, c_dp]),
     'rgp_psi_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),

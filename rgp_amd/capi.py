@@ -114,6 +114,9 @@ class Handle(object):
         return o
 
     # ---- fused layer step ----------------------------------------------------------------------------------------
+    def layer_prepare(self, lin):
+        self._check(self.lib.rgp_layer_prepare(self.h, C.byref(lin)))
+
     def layer_step(self, lin, lout):
         self._check(self.lib.rgp_layer_step(self.h, C.byref(lin), C.byref(lout)))
 

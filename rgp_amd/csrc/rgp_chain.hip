@@ -224,13 +224,6 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
   wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
   // dL_dpsi1 = beta Ymean Kinv_mu^T -> coefficient matrix          (:164-167)
   for (int i = t; i < M * D; i += blockDim.x) c.Cpsi1[i] = beta * c.Kinv_mu[i];
-  // woodbury_inv = Linv^T (I - E E^T) Linv                        (:154)
-  if (c.winv) {
-    for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? 1.0 : 0.0) - c.EEt[i];
-    __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
-    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
-  }
   if (t == 0) {
     c.scal[0] = ldm;      // sum log diag Lm
     c.scal[1] = lds_;     // sum log diag Ls
@@ -303,6 +296,13 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
     for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.Gv[i] + c.Gv[(i % M) * M + i / M];
     __syncthreads();
     wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.qU_W, M, 0.0, c.gqU_W, M, lds);
+  }
+  // woodbury_inv = Linv^T (I - E E^T) Linv                        (:154)
+  if (c.winv) {
+    for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? 1.0 : 0.0) - c.EEt[i];
+    __syncthreads();
+    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
+    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
   }
   double tr = block_sum((t < M) ? c.Gv[t * M + t] : 0.0, scratch);
   if (t == 0) {

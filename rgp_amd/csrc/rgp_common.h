@@ -44,14 +44,18 @@ struct rgp_ctx {
   // layer (side streams) can overlap the psi passes of the next layer (main stream).
   char* ws = nullptr;
   size_t ws_bytes = 0;
-  char* ws_slot[2] = {nullptr, nullptr};
-  size_t ws_slot_bytes[2] = {0, 0};
-  int parity = 0;
+  static const int NSLOT = 4;
+  char* ws_slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  size_t ws_slot_bytes[NSLOT] = {0, 0, 0, 0};
+  int slot_next = 0;                 // next slot to hand out
+  int prepared_head = 0, prepared_count = 0;   // FIFO of slots prepared by rgp_layer_prepare
+  int prepared_slot[NSLOT] = {0, 0, 0, 0};
   bool overlap = true;
   hipStream_t side_pre = nullptr, side_post = nullptr;
-  hipEvent_t ev_prep = nullptr, ev_pre = nullptr, ev_stats = nullptr;
-  hipEvent_t ev_done[2] = {nullptr, nullptr};
-  bool done_recorded[2] = {false, false};
+  hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
+  hipEvent_t ev_pre[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_done[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  bool done_recorded[NSLOT] = {false, false, false, false};
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
   int num_cu = 256;
   // optional profiling of the psi2 launch (rgp_set_profiling)

@@ -15,7 +15,7 @@ rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg) {
 }
 
 void rgp_join_streams(rgp_handle h) {
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < rgp_ctx::NSLOT; ++k)
     if (h->done_recorded[k]) (void)hipStreamWaitEvent(h->stream, h->ev_done[k], 0);
 }
 
@@ -68,10 +68,11 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   if (hipStreamCreateWithFlags(&h->side_pre, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming);
-  hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming);
-  hipEventCreateWithFlags(&h->ev_done[0], hipEventDisableTiming);
-  hipEventCreateWithFlags(&h->ev_done[1], hipEventDisableTiming);
+  for (int k = 0; k < rgp_ctx::NSLOT; ++k) {
+    hipEventCreateWithFlags(&h->ev_pre[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
+  }
   *out = h;
   return RGP_OK;
 }
@@ -83,7 +84,7 @@ extern "C" void rgp_destroy(rgp_handle h) {
   if (h->side_pre) { hipStreamSynchronize(h->side_pre); hipStreamDestroy(h->side_pre); }
   if (h->side_post) { hipStreamSynchronize(h->side_post); hipStreamDestroy(h->side_post); }
   if (h->ws) hipFree(h->ws);
-  for (int k = 0; k < 2; ++k) if (h->ws_slot[k]) hipFree(h->ws_slot[k]);
+  for (int k = 0; k < rgp_ctx::NSLOT; ++k) if (h->ws_slot[k]) hipFree(h->ws_slot[k]);
   if (h->status) hipFree(h->status);
   delete h;
 }
@@ -842,6 +843,51 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
 // ==================================================================================================================
 // the fused layer step
 // ==================================================================================================================
+// Takes the next workspace slot, computes the Z terms on the main stream and starts the data-independent part of the
+// SVI chain on the side stream.  ev_pre[slot] fires when Cpsi1 / dL_dpsi2 / the factors are ready.
+static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* slot_out) {
+  const int M = in->M, D = in->D;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  const int64_t N = in->N;
+  rgp_status st;
+  LayerWs L;
+  SviChain c{};
+  c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
+  const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, &c);
+  const int slot = h->slot_next;
+  h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
+  if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
+  hipStream_t s = h->stream;
+  hipStream_t s_pre = h->overlap ? h->side_pre : s;
+  // the side-stream work that last used this slot must be finished before it is overwritten
+  if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
+  carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
+  launch_prep_z(s, M, Q, L.zt.QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+  c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
+  if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
+  }
+  if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
+  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
+  *slot_out = slot;
+  return RGP_OK;
+}
+
+extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
+  if (!h || !in) return RGP_ERR_BAD_ARG;
+  if (in->mode != RGP_MODE_SVI) return RGP_OK;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  rgp_status st = check_geometry(h, in->N, in->M, Q);
+  if (st) return st;
+  if (h->prepared_count >= rgp_ctx::NSLOT - 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_prepare: too many layers outstanding");
+  int slot;
+  if ((st = svi_prepare_slot(h, in, &slot))) return st;
+  h->prepared_slot[(h->prepared_head + h->prepared_count) % rgp_ctx::NSLOT] = slot;
+  h->prepared_count++;
+  return last_launch(h, "rgp_layer_prepare");
+}
+
 extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
   if (!h || !in || !out) return RGP_ERR_BAD_ARG;
   if (in->mode == RGP_MODE_VARDTC) return vardtc_layer_step(h, in, out);
@@ -857,22 +903,25 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   LayerWs L;
   SviChain c{};
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
-  const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, &c);
-  const int slot = h->parity;
-  h->parity ^= 1;
-  if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
   hipStream_t s = h->stream;
-  // the side-stream work that last used this slot must be finished before the main stream overwrites it
-  if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
-  carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
-  hipStream_t s_pre = h->overlap ? h->side_pre : s, s_post = h->overlap ? h->side_post : s;
+  hipStream_t s_post = h->overlap ? h->side_post : s;
+  int slot;
+  if (h->prepared_count > 0) {                       // K_uu + chain_pre already in flight (rgp_layer_prepare)
+    slot = h->prepared_slot[h->prepared_head];
+    h->prepared_head = (h->prepared_head + 1) % rgp_ctx::NSLOT;
+    h->prepared_count--;
+    carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
+  } else {
+    if ((st = svi_prepare_slot(h, in, &slot))) return st;
+    carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
+  }
+  c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
   const int QP = L.zt.QP;
 
-  // tables + Z terms + rows
+  // tables + rows
   launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
   hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
   if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
-  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
   WindowSpec w{};
   w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
   w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
@@ -881,20 +930,13 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
   launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
 
-  // data-independent algebra
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
   c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv; c.status = h->status;
-  if (h->overlap) {
-    RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
-    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
-  }
-  if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
-  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre, s_pre));
 
   // psi1 side
   launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre, 0));      // Cpsi1 / dL_dpsi2 come from the chain
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));      // Cpsi1 / dL_dpsi2 come from the chain
   {
     const size_t lds = (size_t)M * (D + 1) * sizeof(double);
     int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
@@ -951,7 +993,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (h->overlap) {
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
-    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre, 0));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre[slot], 0));
   }
   if ((st = launch_svi_chain_post(h, c, s_post))) return st;
   {

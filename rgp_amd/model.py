@@ -323,6 +323,7 @@ class DeepAutoreg(object):
         h = self.handle
         n_batch = None
         self._keep = []
+        ios = []
         for k, L in enumerate(self.layers):
             dev, n_seq, N, own_rows, up_rows = self._seq_tables(L, seqs)
             n_batch = n_seq
@@ -360,6 +361,13 @@ class DeepAutoreg(object):
             if i < self.nLayers - 1:
                 lout.g_up_mean, lout.g_up_var = self.gmeans.data_ptr(), self.gvars.data_ptr()
             lout.woodbury_inv, lout.woodbury_vector = self._winv[i].data_ptr(), self._wvec[i].data_ptr()
+            ios.append((lin, lout))
+        # start K_uu / factorisations / the data-independent SVI algebra of every layer now (side stream): they need only
+        # the parameters, and would otherwise sit on the critical path in front of each layer's psi passes
+        if self.svi and len(ios) <= 3:
+            for lin, _ in ios:
+                h.layer_prepare(lin)
+        for lin, lout in ios:
             h.layer_step(lin, lout)
         h.join()                         # global gradients / ELBO of every layer are produced on the library's side streams
         elbo = self._elbo_buf.sum()
