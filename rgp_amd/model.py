@@ -219,6 +219,8 @@ class DeepAutoreg(object):
         self._wvec = {L.index: torch.zeros(L.M, L.D, **f64) for L in self.layers}
         self.opt_array = None
         self._adam = None
+        self.data_streamer = None
+        self.mb_inf_sample_idxes = None
 
     # ------------------------------------------------------------------------------------------------------------
     # host-side helpers used only at construction (setup, not the hot path)
@@ -408,7 +410,21 @@ class DeepAutoreg(object):
         self.param_array[idx] = torch.where(pos, _softplus(x), x)
 
     def objective_and_grad(self, x, seqs=None):
-        """(-ELBO, -dELBO/dx) in optimiser space on the host (paramz' objective_function / _grads)."""
+        """(-ELBO, -dELBO/dx) in optimiser space on the host (paramz' objective_function / _grads).  With a data streamer
+        attached and ``seqs`` None, each call first advances to the streamer's next minibatch (model.py:209-213); ``x`` then
+        covers the globals and the latents of ALL sequences, gradients of untouched sequences are zero."""
+        if seqs is None and self.data_streamer is not None:
+            mb = self._next_minibatch()
+            self.set_optimizer_array(x, None)
+            self.grad_array[self.loc0:].zero_()
+            e = self.evaluate(mb)
+            idx = self._index_set(None)
+            g = self.grad_array[idx]
+            p = self.param_array[idx]
+            pos = self.positive[idx].bool()
+            g = torch.where(pos, g * (-torch.expm1(-p)), g)
+            self.handle.sync()
+            return -float(e.item()), -g.cpu().numpy()
         self.set_optimizer_array(x, seqs)
         e = self.evaluate(seqs)
         idx = self._index_set(seqs)
@@ -426,6 +442,33 @@ class DeepAutoreg(object):
         x, f, d = fmin_l_bfgs_b(self.objective_and_grad, x0, maxfun=max_iters, maxiter=max_iters, iprint=1 if messages else -1)
         self.set_optimizer_array(x)
         return f, d
+
+    # ------------------------------------------------------------------------------------------------------------
+    # minibatch switch (model.py:209-282) and parameter-vector checkpoint (examples/walk_run_2_alex.py:565-576)
+    # ------------------------------------------------------------------------------------------------------------
+    def set_DataStreamer(self, data_streamer):
+        """Attach a streamer (rgp_amd.data_streamers): every objective evaluation through ``objective_and_grad`` /
+        ``optimize`` then sees the streamer's next minibatch, as the overridden ``optimizer_array`` setter does in the
+        reference (model.py:209-213).  The streamer must index the sequences this model was built with."""
+        assert data_streamer.total_size == self.nSeq, 'the streamer must cover the sequences of this model'
+        self.data_streamer = data_streamer
+        self.mb_inf_sample_idxes = list(range(self.nSeq))
+
+    def _next_minibatch(self):
+        _, idx, _, _ = self.data_streamer.next_minibatch()
+        self.mb_inf_sample_idxes = [int(i) for i in idx]
+        return self.mb_inf_sample_idxes
+
+    def save(self, path):
+        """Dump the flat constrained parameter vector (the reference saves ``m.param_array`` to .h5 / .mat)."""
+        self.handle.sync()
+        np.savez(path, param_array=self.param_array.cpu().numpy(), n_global=self.n_global, n_local=self.n_local)
+
+    def load(self, path):
+        d = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        assert int(d['n_global']) == self.n_global and int(d['n_local']) == self.n_local, 'parameter layout mismatch'
+        self.param_array.copy_(torch.as_tensor(d['param_array'], device=self.device))
+        self._adam = None
 
     # ------------------------------------------------------------------------------------------------------------
     # SVI loop: Adam on device (global bucket + the touched sequences' local parameters)

@@ -246,3 +246,31 @@ def test_config4_geometry_matches_oracle_elbo():
     assert abs(e_g - e_o) <= 1e-9 * abs(e_o), (e_g, e_o)
     gz = m.view(m.layers[0], 'Z', grad=True).cpu().numpy()
     assert np.abs(gz - G_o[(m.layers[0].index, 'Z')]).max() <= 1e-7 * np.abs(gz).max()
+
+
+def test_streamer_and_checkpoint(tmp_path):
+    """Minibatch switch through a data streamer (model.py:209-267) and save/load of the flat parameter vector."""
+    from rgp_amd.data_streamers import StdMemoryDataStreamer, TrivialDataStreamer
+    o, g = build_pair(n_seq=4, T=12, n_total=4)
+    x0 = g.get_optimizer_array()
+    f_full, _ = g.objective_and_grad(x0)
+    # trivial streamer: same likelihood as no streamer (testing/minibatch_tests.py:102-107)
+    U, Y = make_data(4, 12)
+    g.set_DataStreamer(TrivialDataStreamer(Y, U))
+    f_triv, g_triv = g.objective_and_grad(x0)
+    assert f_triv == f_full
+    # two half minibatches add up to the full objective (KL is pre-scaled by qU_ratio)
+    g.set_DataStreamer(StdMemoryDataStreamer(Y, U, 2))
+    f1, g1 = g.objective_and_grad(x0)
+    f2, g2 = g.objective_and_grad(x0)
+    assert g.mb_inf_sample_idxes == [2, 3]
+    assert abs((f1 + f2) - f_full) <= 1e-12 * abs(f_full)
+    np.testing.assert_allclose(g1 + g2, g_triv, rtol=1e-8, atol=1e-9)
+    # checkpoint round trip
+    path = str(tmp_path / 'ckpt.npz')
+    g.data_streamer = None
+    g.save(path)
+    g.param_array.mul_(1.01)
+    assert g.objective_and_grad(g.get_optimizer_array())[0] != f_full
+    g.load(path)
+    assert g.objective_and_grad(g.get_optimizer_array())[0] == f_full
