@@ -114,6 +114,20 @@ rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches
  *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);
 
+/* ---- collapsed bound in two phases, for data-parallel use.  The reference's dead MPI stub all-reduces the sufficient
+ *      statistics [psi0, psi2, YRY, psi1Y] (svi_vardtc.py:65-67); for the collapsed bound dL/dpsi2 depends on the GLOBAL
+ *      psi2 (vardtc.py:141-142), so the exchange sits between the forward statistics and the M x M algebra.
+ * rgp_vardtc_stats : forward pass of the local rows; packs [psi0sum, yry, psi2 (M*M), psi1Y (D*M), PsiR (M*M)] into
+ *                    `stats` (device, 2 + 2*M*M + D*M doubles).  The caller sums `stats` over ranks (one all-reduce).
+ * rgp_vardtc_finish: M x M algebra on the summed statistics (N_global = total rows over ranks), then the local backward
+ *                    pass.  Quantities that every rank computes identically (the bound's data-independent part, dL/dnoise,
+ *                    the K_uu backward term) are multiplied by replicated_weight (= 1/world), so that ONE sum all-reduce of
+ *                    [elbo, global gradients] reproduces the single-device result.  Must directly follow rgp_vardtc_stats of
+ *                    the same layer on this handle. */
+rgp_status rgp_vardtc_stats(rgp_handle h, const rgp_layer_in* in, double* stats);
+rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out, double* stats,
+                             int64_t N_global, double replicated_weight);
+
 /* ---- unit-testable pieces (dense, caller-materialised X; replace the GPy kernel protocol) -------------------- */
 /* kern.K(Z) + jitter*I (vardtc.py:110-114). */
 rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,

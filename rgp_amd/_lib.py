@@ -44,6 +44,8 @@ SYMBOLS = {
     'rgp_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     'rgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'rgp_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    'rgp_vardtc_stats': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), c_dp]),
+    'rgp_vardtc_finish': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), C.POINTER(LayerOut), c_dp, C.c_int64, C.c_double]),
     'rgp_layer_prepare': (C.c_int, [C.c_void_p, C.POINTER(LayerIn)]),
     'rgp_layer_step': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), C.POINTER(LayerOut)]),
     'rgp_kuu': (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_double, c_dp]),

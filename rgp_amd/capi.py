@@ -114,6 +114,12 @@ class Handle(object):
         return o
 
     # ---- fused layer step ----------------------------------------------------------------------------------------
+    def vardtc_stats(self, lin, stats):
+        self._check(self.lib.rgp_vardtc_stats(self.h, C.byref(lin), _p(stats)))
+
+    def vardtc_finish(self, lin, lout, stats, N_global, weight):
+        self._check(self.lib.rgp_vardtc_finish(self.h, C.byref(lin), C.byref(lout), _p(stats), int(N_global), float(weight)))
+
     def layer_prepare(self, lin):
         self._check(self.lib.rgp_layer_prepare(self.h, C.byref(lin)))
 

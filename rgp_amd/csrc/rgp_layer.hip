@@ -321,6 +321,7 @@ struct FinalizeArgs {
   const double *dz1;       // [M x QP] psi1 part (may be null)
   const double *dz2;       // [QP x 128] psi2 part, transposed layout (may be null)
   const double *dlam1, *dlam2, *lsum1, *wsum2;    // may be null
+  double dk_scale;         // weight of the K_uu backward term (1, or 1/world for the data-parallel collapsed bound)
   double psi0_coef;        // sum_n dL_dpsi0[n]  (d psi0/d variance = 1)
   const double* psi0_dev;  // optional device scalar c: adds c[0]*psi0_dev_scale (used for -D beta N / 2)
   double psi0_dev_scale;
@@ -341,8 +342,8 @@ __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, doub
     double gk = 0.0, gkT = 0.0, ws = 0.0;
     if (a.dKmm) {
       const double k1 = a.Kj[m * M + mp] - (m == mp ? RGP_JITTER : 0.0);
-      gk = a.dKmm[m * M + mp] * k1;
-      gkT = a.dKmm[mp * M + m] * k1;
+      gk = a.dk_scale * a.dKmm[m * M + mp] * k1;
+      gkT = a.dk_scale * a.dKmm[mp * M + m] * k1;
       if (q == 0) gs += gk;
     }
     if (a.dLs) ws = a.dLs[m * M + mp] * a.psi2[m * M + mp];
@@ -506,13 +507,14 @@ __global__ void __launch_bounds__(256) up_latent_kernel(UpArgs a) {
   }
 }
 
+// w scales the terms that are replicated on every rank of a data-parallel collapsed bound (1 otherwise)
 __global__ void finish_elbo_kernel(const double* bound, const double* part, int npart, const double* dthetaL,
-                                   double* elbo, double* gnoise) {
+                                   double* elbo, double* gnoise, double w) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = bound[0];
+    double s = w * bound[0];
     for (int i = 0; i < npart; ++i) s += part[i];
     elbo[0] = s;
-    if (gnoise) gnoise[0] = dthetaL[0];
+    if (gnoise) gnoise[0] = w * dthetaL[0];
   }
 }
 
@@ -690,7 +692,7 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
   f.dz1 = dL_dpsi1 ? L.dz1 : nullptr; f.dz2 = dL_dpsi2 ? L.dz2 : nullptr;
   f.dlam1 = dL_dpsi1 ? L.dlam1 : nullptr; f.dlam2 = dL_dpsi2 ? L.dlam2 : nullptr;
   f.lsum1 = dL_dpsi1 ? L.lsum1 : nullptr; f.wsum2 = dL_dpsi2 ? L.wsum2 : nullptr;
-  f.psi0_coef = dL_dpsi0_sum; f.psi0_dev = nullptr; f.psi0_dev_scale = 0.0;
+  f.dk_scale = 1.0; f.psi0_coef = dL_dpsi0_sum; f.psi0_dev = nullptr; f.psi0_dev_scale = 0.0;
   f.gZ = dZ; f.ginv_l = dinv_l; f.gvariance = dvar;
   launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
   const int64_t nq = N * Q;
@@ -731,7 +733,11 @@ extern "C" rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, doubl
 // collapsed-bound layer step (VarDTC.inference, vardtc.py:88-208): dL/dpsi2 depends on the statistics, so the psi2
 // kernel runs twice (forward sum, then backward with recomputation) around the M x M chain.
 // ==================================================================================================================
-static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
+// phase 0: whole step with local statistics; 1: statistics only (packed into stats_io); 2: finish with the statistics in
+// stats_io (e.g. after an all-reduce over ranks), N_global rows in total, replicated terms weighted by rep_w.
+// Packed layout: [psi0sum, yry, psi2 (M*M), psi1Y (D*M), PsiR (M*M)].
+static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out, int phase = 0,
+                                    double* stats_io = nullptr, int64_t N_global = 0, double rep_w = 1.0) {
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
@@ -749,15 +755,17 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
   const int QP = L.zt.QP;
   const int tri = M * (M + 1) / 2;
 
-  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
-  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
-  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
-  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
   WindowSpec w{};
   w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
   w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
   w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
   w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+  const size_t mm = (size_t)M * M, dm_ = (size_t)D * M;
+  if (phase != 2) {
+  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
+  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
+  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
   launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
   launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
 
@@ -777,10 +785,24 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
   }
   hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
+  }
+  if (phase == 1) {                                  // hand the local statistics to the caller (vardtc.py:65-67 stub)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io, L.psi0sum, sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 1, L.yry, sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2, L.psi2, mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2 + mm, L.psi1Y, dm_ * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (in->y_uncertain) RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2 + mm + dm_, L.PsiR, mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+    else RGP_HIP_CHECK(h, hipMemsetAsync(stats_io + 2 + mm + dm_, 0, mm * sizeof(double), s));
+    return last_launch(h, "rgp_vardtc_stats");
+  }
 
   // M x M algebra
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
   c.PsiR = L.PsiR; c.winv = out->woodbury_inv; c.status = h->status;
+  if (phase == 2) {                                  // global statistics supplied by the caller
+    c.N = N_global; c.psi0sum = stats_io; c.yry = stats_io + 1; c.psi2 = stats_io + 2; c.psi1Y = stats_io + 2 + mm;
+    c.PsiR = stats_io + 2 + mm + dm_;
+  }
   if ((st = launch_vardtc_chain(h, c))) return st;
   hipLaunchKernelGGL(psi0_coef_beta_kernel, dim3(1), dim3(64), 0, s, N, D, c.beta, L.psi0coef);
 
@@ -814,7 +836,7 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
     f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
     f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
-    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.dk_scale = rep_w; f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
     f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
     launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
   }
@@ -834,7 +856,7 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
   }
   hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
-                     out->gnoise);
+                     out->gnoise, rep_w);
   if (out->woodbury_vector)
     RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.vT, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
   return last_launch(h, "rgp_layer_step(vardtc)");
@@ -872,6 +894,18 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   *slot_out = slot;
   return RGP_OK;
+}
+
+extern "C" rgp_status rgp_vardtc_stats(rgp_handle h, const rgp_layer_in* in, double* stats) {
+  if (!h || !in || !stats || in->mode != RGP_MODE_VARDTC) return RGP_ERR_BAD_ARG;
+  rgp_layer_out dummy{};
+  return vardtc_layer_step(h, in, &dummy, 1, stats);
+}
+
+extern "C" rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out, double* stats,
+                                        int64_t N_global, double replicated_weight) {
+  if (!h || !in || !out || !stats || in->mode != RGP_MODE_VARDTC) return RGP_ERR_BAD_ARG;
+  return vardtc_layer_step(h, in, out, 2, stats, N_global, replicated_weight);
 }
 
 extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
@@ -1001,12 +1035,12 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
     f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2;
     f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
-    f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.dk_scale = 1.0; f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
     f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
     launch_finalize(s_post, f, L.fin_dlrow, L.fin_gsum);
   }
   hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s_post, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
-                     out->gnoise);
+                     out->gnoise, 1.0);
   if (out->woodbury_vector)
     RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.Kinv_mu, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s_post));
   if (h->overlap) {

@@ -318,7 +318,7 @@ class DeepAutoreg(object):
         N = int(own_len.sum() - n_seq * L.X_win)
         return dev, n_seq, N, int(own_len.sum()), int(up_len.sum())
 
-    def evaluate(self, seqs=None, qU_ratio=None):
+    def evaluate(self, seqs=None, qU_ratio=None, stats_allreduce=None, world=1):
         """ELBO and all gradients for the sequences ``seqs`` (None = all, slice, or index list).  Returns the device
         scalar ELBO (also stored in ``grad_array[elbo_slot]``).  Latent gradients are written for the touched sequences
         only."""
@@ -369,8 +369,17 @@ class DeepAutoreg(object):
         if self.svi and len(ios) <= 3:
             for lin, _ in ios:
                 h.layer_prepare(lin)
-        for lin, lout in ios:
-            h.layer_step(lin, lout)
+        if (not self.svi) and stats_allreduce is not None:
+            # data-parallel collapsed bound: one all-reduce of the sufficient statistics per layer (svi_vardtc.py:65-67)
+            for (lin, lout), L in zip(ios, self.layers):
+                stats = torch.empty(2 + 2 * L.M * L.M + L.D * L.M, dtype=torch.float64, device=self.device)
+                ntot = torch.tensor([float(lin.N)], dtype=torch.float64, device=self.device)
+                h.vardtc_stats(lin, stats)
+                stats_allreduce(stats, ntot, L)
+                h.vardtc_finish(lin, lout, stats, int(round(float(ntot.item()))), 1.0 / world)
+        else:
+            for lin, lout in ios:
+                h.layer_step(lin, lout)
         h.join()                         # global gradients / ELBO of every layer are produced on the library's side streams
         elbo = self._elbo_buf.sum()
         self.grad_array[self.elbo_slot] = elbo
