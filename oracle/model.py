@@ -70,7 +70,8 @@ class DeepAutoreg(object):
     ``model.layers`` list (model.py:682-688)."""
 
     def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10,
-                 init='Y', inference_method=None, n_total=None, Zs=None, rng=None, fast_psi=True, chunk=512):
+                 init='Y', inference_method=None, n_total=None, Zs=None, rng=None, fast_psi=True, chunk=512,
+                 latent_full=False):
         rng = np.random.default_rng(0) if rng is None else rng
         Ys = [Y] if isinstance(Y, np.ndarray) else list(Y)
         Us = None if U is None else ([U] if isinstance(U, np.ndarray) else list(U))
@@ -90,12 +91,16 @@ class DeepAutoreg(object):
             self.Us, self.Ys = None, [y.copy() for y in Ys]
         self.nSeq = len(self.Ys)
         self.n_total = self.nSeq if n_total is None else n_total
-        # ---- a2: hidden q(X) (model.py:691-716) ----
+        # ---- a2: hidden q(X) (model.py:691-716).  latent_full: latents produced by a sequence encoder have one row per
+        #      RAW time step (DeepAutoreg_rnn, model.py:427-440) instead of wins[i] + len(Y) rows; windows stay right aligned ----
+        self.latent_full = latent_full
         self.Xmean, self.Xvar = {}, {}
         for i in range(1, self.nLayers):
             ms, vs = [], []
             for y in self.Ys:
                 w, h = self.wins[i], self.nDims[i]
+                if latent_full:
+                    w = (U_win if Us is not None else 0)
                 m = np.zeros((w + y.shape[0], h))
                 if init == 'Y':
                     m[w:] = y[:, :h]
@@ -139,7 +144,7 @@ class DeepAutoreg(object):
         return self.Xmean[i + 1][s], self.Xvar[i + 1][s], self.wins[i + 1]
 
     def _own_len(self, i, s):
-        return self.Ys[s].shape[0] + self.wins[i]
+        return self.Ys[s].shape[0] if i == 0 else self.Xmean[i][s].shape[0]
 
     def build_XY(self, i, seqs):
         X_win = self.wins[i]

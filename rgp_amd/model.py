@@ -74,7 +74,7 @@ class DeepAutoreg(object):
     def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10, likelihood=None,
                  name='autoreg', kernels=None, U_pre_step=True, init='Y', inducing_init='rand', back_cstr=False,
                  MLP_dims=None, inference_method='svi', minibatch_inference=False, mb_inf_tot_data_size=None,
-                 mb_inf_sample_idxes=None, device=None, seed=0, Zs=None):
+                 mb_inf_sample_idxes=None, device=None, seed=0, Zs=None, latent_full=False):
         if back_cstr:
             raise NotImplementedError('back-constraints (autoreg/mlp.py, rnn_encoder.py) are outside this build (SURVEY 8f)')
         if not U_pre_step:
@@ -140,7 +140,10 @@ class DeepAutoreg(object):
         off += 1
         self.loc0 = off
         # latent blocks: element offsets relative to the start of the means region
-        self.lat_len = {i: self.Ly + self.wins[i] for i in range(1, self.nLayers)}
+        # latent_full: one latent row per RAW time step (latents produced by a sequence encoder, model.py:427-440)
+        self.latent_full = latent_full
+        self.lat_len = {i: self.Ly + ((U_win if Us is not None else 0) if latent_full else self.wins[i])
+                        for i in range(1, self.nLayers)}
         self.lat_off = {i: np.zeros(self.nSeq, dtype=np.int64) for i in range(1, self.nLayers)}
         self.seq_loc_off = np.zeros(self.nSeq + 1, dtype=np.int64)
         o = 0
@@ -174,7 +177,7 @@ class DeepAutoreg(object):
                 T = int(self.lat_len[i][s])
                 blk = np.zeros((T, H))
                 if init == 'Y':
-                    blk[w:] = Ys[s][:, :H]
+                    blk[T - int(self.Ly[s]):] = Ys[s][:, :H]
                 elif init == 'rand':
                     blk[:] = rng.standard_normal(blk.shape)
                 elif init == 'zero':
@@ -234,7 +237,7 @@ class DeepAutoreg(object):
         rows = []
         w = self.wins[i]
         for s in range(self.nSeq):
-            N = int(self.Ly[s])
+            N = int(self.Ly[s]) if i == 0 else int(self.lat_len[i][s]) - w
             cols = []
             if w > 0:
                 own = self._host_latent(i, s, means)[:-1]
@@ -584,3 +587,96 @@ class DeepAutoreg(object):
 
 
 DeepAutoreg_new = DeepAutoreg
+
+
+class DeepAutoreg_rnn(DeepAutoreg):
+    """autoreg.DeepAutoreg_rnn (model.py:284-629): q(X) of every hidden layer is produced by a recurrent encoder from the
+    raw sequences (equal lengths, stacked to (T, batch, D_y + D_u) as at model.py:429), so the latents are NOT free
+    parameters; the trainable parameters are the GP globals and the encoder weights.  The GP layers run through
+    librgp_hip.so exactly as in DeepAutoreg (latents with one row per raw time step); the encoder is PyTorch-ROCm fp64."""
+
+    def __init__(self, wins, Y, U=None, U_win=1, nDims=None, num_inducing=10, kernels=None, rnn_type='rnn',
+                 rnn_hidden_dims=None, rnn_bidirectional=False, inference_method='svi', mb_inf_tot_data_size=None,
+                 device=None, seed=0, Zs=None, **kw):
+        from .rnn_encoder import SeqEncoder
+        Ys = [Y] if isinstance(Y, np.ndarray) else list(Y)
+        Us = None if U is None else ([U] if isinstance(U, np.ndarray) else list(U))
+        assert len(set(y.shape[0] for y in Ys)) == 1, 'the sequence encoder needs equal-length sequences (model.py:429)'
+        DeepAutoreg.__init__(self, wins, Ys, U=Us, U_win=U_win, nDims=nDims, num_inducing=num_inducing, kernels=kernels,
+                             init='Y', inference_method=inference_method, mb_inf_tot_data_size=mb_inf_tot_data_size,
+                             device=device, seed=seed, Zs=Zs, latent_full=True, **kw)
+        torch.manual_seed(seed)
+        in_dims = list(self.nDims[:-1])
+        in_dims[0] += (Us[0].shape[1] if Us is not None else 0)              # encode_include_input (model.py:409-412)
+        hid = rnn_hidden_dims[0] if rnn_hidden_dims is not None else 10
+        self.encoder = SeqEncoder(in_dims, self.nDims[1:], hid, rnn_type, rnn_bidirectional).to(self.device)
+        raw = np.stack([np.hstack([y, u]) if Us is not None else y for y, u in zip(Ys, Us or Ys)], axis=1)
+        self.enc_input = torch.as_tensor(raw, dtype=torch.float64, device=self.device)       # (T, n_seq, D_y + D_u)
+        # flat offsets of (t, s, h) of hidden layer i inside the means / vars regions
+        self._enc_index = {}
+        for i in range(1, self.nLayers):
+            H = self.nDims[i]
+            T = int(self.lat_len[i][0])
+            base = torch.as_tensor(self.lat_off[i], device=self.device).view(1, -1, 1)
+            t = torch.arange(T, device=self.device).view(-1, 1, 1) * H
+            hh = torch.arange(H, device=self.device).view(1, 1, -1)
+            self._enc_index[i] = (base + t + hh)                                             # (T, n_seq, H)
+        self._enc_out = None
+
+    def encode(self, seqs=None):
+        """Run the encoder on the sequences ``seqs`` and write q(X) of every hidden layer into the latent buffers."""
+        idx = slice(None) if seqs is None else (seqs if isinstance(seqs, slice) else torch.as_tensor(list(seqs), device=self.device))
+        means, variances = self.encoder(self.enc_input[:, idx, :])
+        with torch.no_grad():
+            for l, (m, v) in enumerate(zip(means, variances)):
+                flat = self._enc_index[l + 1][:, idx, :].reshape(-1)
+                self.means[flat] = m.reshape(-1)
+                self.vars[flat] = v.reshape(-1)
+        self._enc_out = (means, variances, idx)
+        return means, variances
+
+    def evaluate(self, seqs=None, qU_ratio=None, **kw):
+        """ELBO and gradients: GP globals in grad_array, encoder weights in ``.grad`` (model.py:525-551)."""
+        self.encode(seqs)
+        means, variances, idx = self._enc_out
+        elbo = DeepAutoreg.evaluate(self, seqs, qU_ratio=qU_ratio, **kw)
+        self.encoder.zero_grad()
+        outs, grads = [], []
+        for l, (m, v) in enumerate(zip(means, variances)):
+            flat = self._enc_index[l + 1][:, idx, :].reshape(-1)
+            outs += [m, v]
+            grads += [self.gmeans[flat].view(m.shape), self.gvars[flat].view(v.shape)]
+        torch.autograd.backward(outs, grads)                                               # rnn_encoder.py:274
+        self._enc_out = None
+        return elbo
+
+    def encoder_grad_vector(self):
+        return torch.cat([p.grad.reshape(-1) for p in self.encoder.parameters()])
+
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True):
+        """One SVI step: ELBO + gradients, optional all-reduce (global GP bucket and encoder-weight gradients, both
+        replicated parameters), Adam on the GP globals (device kernel) and on the encoder weights (torch.optim.Adam)."""
+        if self._adam is None:
+            self._init_adam()
+            self._enc_opt = torch.optim.Adam(self.encoder.parameters(), lr=lr, maximize=True)
+        ad, h = self._adam, self.handle
+        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        if allreduce is not None:
+            allreduce(self.grad_array[:self.n_global + 1])
+            flat = self.encoder_grad_vector()
+            allreduce(flat)
+            o = 0
+            for p in self.encoder.parameters():
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            elbo = self.grad_array[self.elbo_slot]
+        if not update:
+            return elbo
+        ad['t_glob'] += 1
+        G = self.n_global
+        h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
+                    self.positive[:G], lr, ad['t_glob'])
+        for g in self._enc_opt.param_groups:
+            g['lr'] = lr
+        self._enc_opt.step()
+        return elbo

@@ -1,0 +1,103 @@
+"""Sequence-encoder back-constraint (autoreg.DeepAutoreg_rnn): the GP part on the device matches the oracle on the
+encoder-produced q(X) (latents with one row per raw time step), encoder-weight gradients pass a finite-difference check
+(the reference's gate, testing/rnn_rgp_test.py:112), and everything is additive over minibatches (rnn_rgp_test.py:160-168)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_model import make_data
+
+
+def build(rnn_type='rnn', n_seq=3, T=12, bidirectional=False, n_total=None):
+    from rgp_amd.model import DeepAutoreg_rnn
+    U, Y = make_data(n_seq, T, seed=4)
+    m = DeepAutoreg_rnn([0, 3, 3], Y, U=U, U_win=2, nDims=[3, 2, 3], num_inducing=4, rnn_type=rnn_type,
+                        rnn_hidden_dims=[5], rnn_bidirectional=bidirectional, inference_method='svi',
+                        mb_inf_tot_data_size=n_total, seed=1)
+    rng = np.random.default_rng(2)
+    for L in m.layers:
+        m.set_param(L, 'inv_l', 0.3 + rng.random(L.Q))
+        m.set_param(L, 'noise', 0.2 + 0.1 * rng.random())
+        m.set_param(L, 'qU_W', rng.standard_normal((L.M, L.M)) * 0.2)
+        m.set_param(L, 'qU_a', 0.3)
+    return m, U, Y
+
+
+@pytest.mark.parametrize('rnn_type', ['rnn', 'lstm', 'gru'])
+def test_gp_part_matches_oracle_on_encoder_latents(rnn_type):
+    from oracle import model as om
+    m, U, Y = build(rnn_type)
+    e = float(m.evaluate().item())
+    m.handle.sync()
+    o = om.DeepAutoreg([0, 3, 3], Y, U=U, U_win=2, nDims=[3, 2, 3], num_inducing=4, init='Y', inference_method='svi',
+                       rng=np.random.default_rng(0), fast_psi=False, latent_full=True)
+    for L in m.layers:
+        p = o.P[L.index]
+        for nm in ('Z', 'inv_l', 'qU_m', 'qU_W'):
+            getattr(p, nm)[...] = m.view(L, nm).cpu().numpy()
+        p.variance = float(m.view(L, 'variance').item()); p.noise = float(m.view(L, 'noise').item())
+        p.qU_a = float(m.view(L, 'qU_a').item())
+    for i in (1, 2):
+        for s in range(3):
+            assert o.Xmean[i][s].shape == (12, m.nDims[i])
+            o.Xmean[i][s][...] = m.latent(i, s).cpu().numpy()
+            o.Xvar[i][s][...] = m.latent(i, s, var=True).cpu().numpy()
+    eo, Go = o.elbo_and_grads()
+    assert abs(e - eo) <= 1e-11 * abs(eo), (e, eo)
+    for i in (1, 2):
+        for s in range(3):
+            np.testing.assert_allclose(m.latent(i, s, grad=True).cpu().numpy(), Go[(i, 'Xmean', s)], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(m.latent(i, s, var=True, grad=True).cpu().numpy(), Go[(i, 'Xvar', s)], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(m.view(m.layers[0], 'Z', grad=True).cpu().numpy(), Go[(m.layers[0].index, 'Z')], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('rnn_type,bi', [('rnn', False), ('gru', True)])
+def test_encoder_weight_gradients_fd(rnn_type, bi):
+    import torch
+    m, U, Y = build(rnn_type, bidirectional=bi)
+    m.evaluate()
+    m.handle.sync()
+    g = m.encoder_grad_vector().cpu().numpy().copy()
+    params = list(m.encoder.parameters())
+    rng = np.random.default_rng(7)
+    eps = 1e-6
+    off = 0
+    for p in params:
+        n = p.numel()
+        for _ in range(2):
+            j = int(rng.integers(n))
+            def setv(val):
+                with torch.no_grad():
+                    p.view(-1)[j] = val
+            old = float(p.view(-1)[j].item())
+            setv(old + eps); ep = float(m.evaluate().item())
+            setv(old - eps); em = float(m.evaluate().item())
+            setv(old)
+            num = (ep - em) / (2 * eps)
+            assert abs(num - g[off + j]) <= 2e-5 * max(1.0, abs(num)), (off + j, num, g[off + j])
+        off += n
+
+
+def test_minibatch_additivity_including_encoder():
+    m, U, Y = build('lstm', n_seq=4, n_total=4)
+    e_all = float(m.evaluate().item()); g_all = m.grad_array[:m.n_global].cpu().numpy().copy()
+    ge_all = m.encoder_grad_vector().cpu().numpy().copy()
+    e1 = float(m.evaluate(slice(0, 2)).item()); g1 = m.grad_array[:m.n_global].cpu().numpy().copy()
+    ge1 = m.encoder_grad_vector().cpu().numpy().copy()
+    e2 = float(m.evaluate([2, 3]).item()); g2 = m.grad_array[:m.n_global].cpu().numpy().copy()
+    ge2 = m.encoder_grad_vector().cpu().numpy().copy()
+    m.handle.sync()
+    assert abs(e1 + e2 - e_all) <= 1e-12 * abs(e_all)
+    np.testing.assert_allclose(g1 + g2, g_all, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(ge1 + ge2, ge_all, rtol=1e-8, atol=1e-10)
+
+
+def test_svi_steps_improve_the_bound():
+    m, U, Y = build('gru', n_seq=4, n_total=4)
+    e0 = float(m.evaluate().item())
+    for k in range(30):
+        m.svi_step(slice(0, 4), lr=5e-3)
+    e1 = float(m.evaluate().item())
+    m.handle.sync()
+    assert np.isfinite(e1) and e1 > e0, (e0, e1)
