@@ -316,3 +316,28 @@ def test_collapsed_bound_data_parallel_two_shards():
     # local (latent) gradients need no exchange
     np.testing.assert_allclose(A.latent(1, 0, grad=True).cpu().numpy(), full.latent(1, 0, grad=True).cpu().numpy(), rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(B.latent(2, 1, var=True, grad=True).cpu().numpy(), full.latent(2, 3, var=True, grad=True).cpu().numpy(), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('inference', ['svi', None])
+@pytest.mark.parametrize('cfg', [
+    dict(n_seq=1, T=6, wins=(0, 3), nDims=(1, 1), M=1, U_win=2, u_dim=1, y_dim=1),          # one sequence, one inducing point, N = 4 / 1 rows
+    dict(n_seq=2, T=5, wins=(0, 2, 2), nDims=(2, 1, 1), M=2, U_win=1, u_dim=1, y_dim=2),     # shortest usable sequences, U_win = 1
+    dict(n_seq=1, T=40, wins=(0, 8), nDims=(4, 4), M=128, U_win=8, u_dim=4, y_dim=4),         # maximum sizes: M = 128, Q = 64
+    dict(n_seq=3, T=9, wins=(0, 1, 1), nDims=(1, 1, 1), M=3, U_win=1, u_dim=1, y_dim=1),      # windows of one step: Q = 2 / 1
+])
+def test_edge_geometries(cfg, inference):
+    """Minimal, degenerate and maximal geometries of the layer step (both bounds)."""
+    o, g = build_pair(inference=inference, **cfg)
+    compare(o, g, rtol=1e-8)
+
+
+def test_unsupported_sizes_fail_loudly():
+    from rgp_amd._lib import RgpError
+    from rgp_amd.model import DeepAutoreg
+    U, Y = make_data(1, 40, u_dim=1, y_dim=1)
+    m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=129, inference_method='svi')   # M > 128
+    with pytest.raises(RgpError):
+        m.evaluate()
+    m2 = DeepAutoreg([0, 40], Y[:1], U=U[:1], U_win=30, nDims=[1, 1], num_inducing=4, inference_method='svi')   # Q = 70 > 64
+    with pytest.raises(RgpError):
+        m2.evaluate()
