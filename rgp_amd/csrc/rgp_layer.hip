@@ -565,9 +565,9 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.psi2 = ws.take<double>((size_t)M * M); L.dLs = ws.take<double>((size_t)M * M);
   L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
   L.dz2_part = ws.take<double>((size_t)2 * L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
-  L.dlam1_part = ws.take<double>((size_t)L.nblk1 * QP); L.dlam1 = ws.take<double>(QP);
+  L.dlam1_part = ws.take<double>((size_t)PSI1_ROWS_MAXBLK * QP); L.dlam1 = ws.take<double>(QP);     // PSI1_ROWS_MAXBLK >= NBLK1
   L.dlam2_part = ws.take<double>((size_t)2 * L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
-  L.lsum1_part = ws.take<double>(L.nblk1); L.lsum1 = ws.take<double>(1);
+  L.lsum1_part = ws.take<double>(PSI1_ROWS_MAXBLK); L.lsum1 = ws.take<double>(1);
   L.wsum2_part = ws.take<double>((size_t)2 * L.nblk2); L.wsum2 = ws.take<double>(1);
   L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
   L.psi1Y_part = ws.take<double>((size_t)L.nblk1 * (D > 0 ? D : 1) * M); L.psi1Y = ws.take<double>((size_t)(D > 0 ? D : 1) * M);
@@ -969,22 +969,31 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv; c.status = h->status;
 
   // psi1 side
-  launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));      // Cpsi1 / dL_dpsi2 come from the chain
-  {
-    const size_t lds = (size_t)M * (D + 1) * sizeof(double);
-    int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
-    hipLaunchKernelGGL(svi_rows_kernel, dim3((unsigned)b), dim3(256), lds, s, N, M, D, L.Ym, c.Cpsi1, L.psi1, in->noise,
-                       L.Lp /* dLdpsi1, overwritten in place by Lp below */, in->y_uncertain ? L.dYm : nullptr);
-  }
-  {
+  if (psi1_svi_supported(D)) {
+    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));    // Cpsi1 / dL_dpsi2 come from the chain
+    launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
+                    in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
+    const int rb = psi1_svi_rows_blocks(N);
+    launch_reduce(s, L.nblk1, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
+    launch_reduce(s, rb, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
+    launch_reduce(s, rb, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
+    launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+  } else {
+    launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
+    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));
+    {
+      const size_t lds = (size_t)M * (D + 1) * sizeof(double);
+      int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
+      hipLaunchKernelGGL(svi_rows_kernel, dim3((unsigned)b), dim3(256), lds, s, N, M, D, L.Ym, c.Cpsi1, L.psi1, in->noise,
+                         L.Lp /* dLdpsi1, overwritten in place by Lp below */, in->y_uncertain ? L.dYm : nullptr);
+    }
     launch_colmm(s, N, D, M, L.Ym, L.psi1, nullptr, L.psi1Y_part, L.psi1Y, L.nblk1);
+    launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
+    launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
+    launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
+    launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
+    launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
   }
-  launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
-  launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
-  launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
-  launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
-  launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
 
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);

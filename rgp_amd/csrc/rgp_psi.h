@@ -58,6 +58,13 @@ void launch_psi1_bwd(hipStream_t s, int64_t N, int M, int Q, const ZTerms& zt, c
 // dZ partials [nblk x M x QP] of the psi1 term
 void launch_psi1_dz(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, const double* Lp,
                     double* dz_part, int nblk);
+// SVI psi1 side in three passes (forward + Lp + psi1Y partials, row gradients, dZ partials); D <= 16
+#define PSI1_ROWS_MAXBLK 1024
+bool psi1_svi_supported(int D);
+int psi1_svi_rows_blocks(int64_t N);
+void launch_psi1_svi(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms& zt, const RowTerms& rt, const double* Ym,
+                     const double* Cpsi1, const double* noise, double* P, double* Lp, double* psi1Y_part, double* gmu,
+                     double* gS, double* dYm, double* dlam_part, double* lsum_part, double* dz_part, int nblk);
 // fused psi2 pass: forward sum (tri-packed partials) and/or backward for given symmetric dLs (M x M)
 struct Psi2Out {
   double* p2_part;     // [nblk x tri]           (forward)

@@ -235,7 +235,7 @@ void launch_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const Ro
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// psi1 backward (row part): one wave per row.
+// psi1 backward (row part): one wave per group of 4 rows.
 //   Lp[m] = dL_dpsi1[n,m] psi1[n,m];  s0 = sum Lp;  s1[q] = sum Lp z[m,q];  s2[q] = sum Lp z[m,q]^2
 //   dmu = -e (mu s0 - s1);  dS = 1/2 e^2 S2 - 1/2 e s0 with S2 = mu^2 s0 - 2 mu s1 + s2
 //   dinv_l[q] += -1/2 (e/lam)^2 S2 - 1/2 s0 (1 - e/lam)/lam
@@ -255,41 +255,64 @@ __global__ void __launch_bounds__(256) psi1_bwd_kernel(int64_t N, int M, int Q, 
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wpb = blockDim.x >> 6;
-  double* lp = lps + (size_t)wave * M;
   double dl_acc = 0.0;                      // lane q (QP <= 64)
   double ls_acc = 0.0;
-  for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < N; r += (int64_t)gridDim.x * wpb) {
-    double s0 = 0.0;
-    for (int m = lane; m < M; m += 64) {
-      const double v = dLdpsi1[r * M + m] * psi1[r * M + m];
-      lp[m] = v;
-      Lp[r * M + m] = v;
-      s0 += v;
+  // A wave takes PB rows at a time: the Lp values of a row live in two registers per lane (m = lane, lane + 64) and are
+  // broadcast with v_readlane, so one LDS read of z[m, q] serves PB rows and the PB accumulation chains are independent.
+  constexpr int PB = 4;
+  const int64_t ngroups = (N + PB - 1) / PB;
+  for (int64_t gidx = (int64_t)blockIdx.x * wpb + wave; gidx < ngroups; gidx += (int64_t)gridDim.x * wpb) {
+    const int64_t rb = gidx * PB;
+    double l0[PB], l1[PB], s0[PB], s1[PB], s2[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      const int64_t r = rb + b;
+      const bool ok = r < N;
+      l0[b] = (ok && lane < M) ? dLdpsi1[r * M + lane] * psi1[r * M + lane] : 0.0;
+      l1[b] = (ok && lane + 64 < M) ? dLdpsi1[r * M + lane + 64] * psi1[r * M + lane + 64] : 0.0;
+      if (ok && lane < M) Lp[r * M + lane] = l0[b];
+      if (ok && lane + 64 < M) Lp[r * M + lane + 64] = l1[b];
+      s0[b] = wave_sum(l0[b] + l1[b]);
+      s1[b] = 0.0; s2[b] = 0.0;
     }
-    s0 = wave_sum(s0);
-    ls_acc += s0;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    ls_acc += (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    const int q = lane < QP ? lane : QP - 1;
+    const int Ma = M < 64 ? M : 64;
+    for (int m = 0; m < Ma; ++m) {
+      const double z = zs[m * QP + q], zz = z * z;
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const double l = readlane_f64(l0[b], m);
+        s1[b] += l * z;
+        s2[b] += l * zz;
+      }
+    }
+    for (int m = 64; m < M; ++m) {
+      const double z = zs[m * QP + q], zz = z * z;
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const double l = readlane_f64(l1[b], m - 64);
+        s1[b] += l * z;
+        s2[b] += l * zz;
+      }
+    }
     if (lane < QP) {
-      const int q = lane;
-      double s1 = 0.0, s2 = 0.0;
-      for (int m = 0; m < M; ++m) {
-        const double z = zs[m * QP + q], l = lp[m];
-        s1 += l * z;
-        s2 += l * z * z;
-      }
-      const double mu = Xmu[r * QP + q], e = e1[r * QP + q];
-      const double S2 = mu * mu * s0 - 2.0 * mu * s1 + s2;
-      gmu[r * QP + q] = -e * (mu * s0 - s1);
-      gS[r * QP + q] = 0.5 * e * e * S2 - 0.5 * e * s0;
-      if (q < Q) {
-        const double il = 1.0 / lam[q];
-        const double el = e * il;
-        dl_acc += -0.5 * el * el * S2 - 0.5 * s0 * (1.0 - el) * il;
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const int64_t r = rb + b;
+        if (r < N) {
+          const double mu = Xmu[r * QP + q], e = e1[r * QP + q];
+          const double S2 = mu * mu * s0[b] - 2.0 * mu * s1[b] + s2[b];
+          gmu[r * QP + q] = -e * (mu * s0[b] - s1[b]);
+          gS[r * QP + q] = 0.5 * e * e * S2 - 0.5 * e * s0[b];
+          if (q < Q) {
+            const double il = 1.0 / lam[q];
+            const double el = e * il;
+            dl_acc += -0.5 * el * el * S2 - 0.5 * s0[b] * (1.0 - el) * il;
+          }
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   }
   if (lane < QP) dl_s[wave * QP + lane] = dl_acc;
   const double ls_tot = block_sum(lane == 0 ? ls_acc : 0.0, scratch);
@@ -369,6 +392,368 @@ void launch_psi1_dz(hipStream_t s, int64_t N, int M, const ZTerms& zt, const Row
                     double* dz_part, int nblk) {
   const size_t lds = ((size_t)DZ_TILE * M + 2 * (size_t)DZ_TILE * zt.QP) * sizeof(double);
   hipLaunchKernelGGL(psi1_dz_kernel, dim3(nblk), dim3(256), lds, s, N, M, zt.QP, zt.Zc, rt.Xmu, rt.e1, Lp, dz_part);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// psi1 side of the SVI bound in three passes (svi_vardtc.py:150-200 + GPy psi_comp rbf_psi_comp.py psi1 terms).
+// dL/dpsi1 = Ym Cpsi1^T does not depend on the statistics, so the forward value never has to be re-read:
+//   pass F (thread = inducing row m):  P = psi1, Lp = P * (Ym Cpsi1^T) (stored), psi1Y = Ym^T P (per-workgroup partials)
+//   pass R (thread = data row n):      s0, s1[q], s2[q] = sum_m Lp {1, z, z^2}  -> gmu, gS, dinv_l;  dYm = P Cpsi1 - beta Ym
+//   pass Z (thread = inducing row m):  dZ[m,q] = sum_n Lp[n,m] (e mu - e z)[n,q]
+// Each layout makes one of the two reductions thread-local.  Row operands that are uniform over a workgroup (e, e*mu, Ym)
+// are staged in LDS and read as broadcasts: 2*QP doubles per row do not fit the SGPR file (the scalar-operand version of
+// the forward spilled 105 SGPRs per row through v_writelane and ran 5 load-wait phases per row).
+// ------------------------------------------------------------------------------------------------------------------
+#define P1_TILE 32                 // rows staged per tile, 16 per team of 128 threads
+
+template <int QP, int DP>
+__global__ void __launch_bounds__(256, 2)
+psi1_svi_fwd_kernel(const int64_t N, const int M, const int D, const double* __restrict__ Zc, const double* __restrict__ e1,
+                    const double* __restrict__ em, const double* __restrict__ g1, const double* __restrict__ Ym,
+                    const double* __restrict__ Cpsi1, double* __restrict__ P, double* __restrict__ Lp,
+                    double* __restrict__ psi1Y_part) {
+  constexpr int EE = P1_TILE * QP;                                  // double2 entries
+  constexpr int CB = DP * RGP_PSI2_TEAM;                            // doubles needed to combine the teams
+  constexpr int NB = (2 * EE > CB) ? 2 * EE : CB;
+  __shared__ __attribute__((aligned(16))) double buf[NB];
+  __shared__ double ys[P1_TILE * DP];
+  __shared__ double gs[P1_TILE];
+  double2* ee = reinterpret_cast<double2*>(buf);
+  const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1), team = t >> 7;
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  double z[QP], c[DP], py[DP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) z[q] = Zc[(size_t)tm * QP + q];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    c[d] = d < D ? Cpsi1[(size_t)tm * D + d] : 0.0;
+    py[d] = 0.0;
+  }
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
+    const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
+    __syncthreads();
+    {                                             // branch-free staging: all loads of the tile are in flight together
+      const int64_t lim = (int64_t)nr * QP - 1;
+      double2 v[QP / 8];
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) {
+        const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
+        v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
+      }
+      const int yr = (t / DP < nr) ? t / DP : nr - 1, yd = t % DP;
+      const double yv = (t < P1_TILE * DP && yd < D) ? Ym[(rb + yr) * D + (yd < D ? yd : 0)] : 0.0;
+      const double gv = g1[rb + (t < nr ? t : nr - 1)];
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+      if (t < P1_TILE * DP) ys[t] = yv;
+      if (DP > 8 && t + 256 < P1_TILE * DP) {
+        const int i2 = t + 256, r2 = (i2 / DP < nr) ? i2 / DP : nr - 1, d2 = i2 % DP;
+        ys[i2] = d2 < D ? Ym[(rb + r2) * D + d2] : 0.0;
+      }
+      if (t < P1_TILE) gs[t] = gv;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = team; r < nr; r += 2) {
+      const double2* er = ee + r * QP;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; q += 2) {
+        const double2 x0 = er[q], x1 = er[q + 1];
+        a0 += z[q] * (x0.x * z[q] - 2.0 * x0.y);
+        a1 += z[q + 1] * (x1.x * z[q + 1] - 2.0 * x1.y);
+      }
+      const double p = exp(gs[r] - 0.5 * (a0 + a1));
+      double dl = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double y = ys[r * DP + d];
+        dl += y * c[d];
+        py[d] += y * p;
+      }
+      if (act) {
+        Lp[(rb + r) * M + tr] = dl * p;
+        if (P) P[(rb + r) * M + tr] = p;
+      }
+    }
+  }
+  // psi1Y partial of this workgroup: team 0 + team 1 (fixed order)
+  __syncthreads();
+  if (team == 1) {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) buf[d * RGP_PSI2_TEAM + tr] = py[d];
+  }
+  __syncthreads();
+  if (team == 0 && act) {
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+      if (d < D) psi1Y_part[((size_t)blockIdx.x * D + d) * M + tr] = py[d] + buf[d * RGP_PSI2_TEAM + tr];
+  }
+}
+
+template <int QP>
+__global__ void __launch_bounds__(256, 2)
+psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
+                   const double* __restrict__ em, const double* __restrict__ Lp, double* __restrict__ dz_part) {
+  constexpr int EE = P1_TILE * QP;
+  constexpr int CB = QP * RGP_PSI2_TEAM;
+  constexpr int NB = (2 * EE > CB) ? 2 * EE : CB;
+  __shared__ __attribute__((aligned(16))) double buf[NB];
+  __shared__ double lt[(P1_TILE / 2) * 256];
+  double2* ee = reinterpret_cast<double2*>(buf);
+  const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1), team = t >> 7;
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  double z[QP], acc[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    z[q] = Zc[(size_t)tm * QP + q];
+    acc[q] = 0.0;
+  }
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
+    const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
+    // this thread's Lp values of the tile are parked in a private LDS column (loaded and consumed by the same thread)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double lv[P1_TILE / 4];
+#pragma unroll
+      for (int k = 0; k < P1_TILE / 4; ++k) {
+        const int r = team + 2 * (k + h * (P1_TILE / 4));
+        lv[k] = Lp[(rb + (r < nr ? r : nr - 1)) * M + tm];
+      }
+#pragma unroll
+      for (int k = 0; k < P1_TILE / 4; ++k) {
+        const int r = team + 2 * (k + h * (P1_TILE / 4));
+        lt[(k + h * (P1_TILE / 4)) * 256 + t] = (act && r < nr) ? lv[k] : 0.0;
+      }
+    }
+    {
+      const int64_t lim = (int64_t)nr * QP - 1;
+      double2 v[QP / 8];
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) {
+        const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
+        v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < P1_TILE / 2; ++k) {
+      const int r = team + 2 * k;
+      if (r < nr) {
+        const double2* er = ee + r * QP;
+        const double lp = lt[k * 256 + t];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) {
+          const double2 x = er[q];
+          acc[q] += lp * (x.y - x.x * z[q]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (team == 1) {
+#pragma unroll
+    for (int q = 0; q < QP; ++q) buf[q * RGP_PSI2_TEAM + tr] = acc[q];
+  }
+  __syncthreads();
+  if (team == 0 && act) {
+#pragma unroll
+    for (int q = 0; q < QP; ++q) dz_part[((size_t)blockIdx.x * M + tr) * QP + q] = acc[q] + buf[q * RGP_PSI2_TEAM + tr];
+  }
+}
+
+// pass R: lane = data row, the two waves of a workgroup take one half of the q columns each for the same 64 rows;
+// z[m, half] and Cpsi1[m,:] are wave-uniform scalar operands.  Row-major [rows x cols] arrays are read and written
+// through 64 x 16 LDS tiles (global side: 16 lanes per row = 128 contiguous bytes; LDS side: one row per lane), because a
+// direct per-lane walk along a row touches 64 cache lines per load and moved 16x the bytes through L2 (586 us vs 50).
+#define P1_RT 17                   // LDS tile row stride (doubles)
+static __device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int QP, int DP, bool DY>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2)))
+psi1_svi_rows_kernel(const int64_t N, const int M, const int Q, const int D, const double* __restrict__ Zc,
+                     const double* __restrict__ lam, const double* __restrict__ Xmu, const double* __restrict__ e1,
+                     const double* __restrict__ Lp, const double* __restrict__ P, const double* __restrict__ Cpsi1,
+                     const double* __restrict__ Ym, const double* __restrict__ noise, double* __restrict__ gmu,
+                     double* __restrict__ gS, double* __restrict__ dYm, double* __restrict__ dlam_part,
+                     double* __restrict__ lsum_part) {
+  constexpr int QH = QP / 2;
+  // sweep: two 64 x 16 tiles (Lp chunk, P chunk); epilogue: per wave one 64 x (16 + 16) tile of s1 | s2 columns plus s0
+  __shared__ double shbuf[2 * (64 * 2 * P1_RT) + 2 * 64];
+  double* const tl0 = shbuf;
+  double* const tl1 = shbuf + 64 * P1_RT;
+  __shared__ double dl_s[QP];
+  __shared__ double scratch[16];
+  const int t = threadIdx.x, lane = t & 63;
+  const int half = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int qo = half * QH;
+  double ls_acc = 0.0;
+  if (t < QP) dl_s[t] = 0.0;
+  __syncthreads();
+  const int64_t ngroups = (N + 63) / 64;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t n0 = g * 64, n = n0 + lane;
+    const bool ok = n < N;
+    double s0 = 0.0, s1[QH], s2[QH], dy[DP];
+#pragma unroll
+    for (int k = 0; k < QH; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+#pragma unroll
+    for (int d = 0; d < DP; ++d) dy[d] = 0.0;
+    for (int m0 = 0; m0 < M; m0 += 16) {
+      double lv[8], pv[8];
+      bool vm[8];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = t + 128 * k, row = i >> 4, col = i & 15;
+        const bool valid = (n0 + row < N) && (m0 + col < M);
+        const int64_t src = (valid ? n0 + row : N - 1) * M + (valid ? m0 + col : 0);     // clamped: no branch around the load
+        lv[k] = Lp[src];
+        if (DY) pv[k] = P[src];
+        vm[k] = valid;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = t + 128 * k, row = i >> 4, col = i & 15;
+        tl0[row * P1_RT + col] = vm[k] ? lv[k] : 0.0;
+        if (DY) tl1[row * P1_RT + col] = vm[k] ? pv[k] : 0.0;
+      }
+      __syncthreads();
+      const int mc = (M - m0 < 16) ? (M - m0) : 16;
+#pragma unroll 2
+      for (int j = 0; j < mc; ++j) {
+        const double* __restrict__ zr = Zc + (size_t)(m0 + j) * QP + qo;
+        const double lp = tl0[lane * P1_RT + j];
+        s0 += lp;
+#pragma unroll
+        for (int k = 0; k < QH; ++k) {
+          const double lz = lp * zr[k];
+          s1[k] += lz;
+          s2[k] += lz * zr[k];
+        }
+        if (DY && half == 0) {
+          const double p = tl1[lane * P1_RT + j];
+#pragma unroll
+          for (int d = 0; d < DP; ++d) dy[d] += p * (d < D ? Cpsi1[(size_t)(m0 + j) * D + d] : 0.0);
+        }
+      }
+    }
+    if (!ok) s0 = 0.0;
+    if (half == 0) ls_acc += s0;
+    // epilogue: transpose s0, s1, s2 through a wave-private LDS tile, then work element-wise in the coalesced layout
+    // (16 lanes per row): mu, e are read and gmu, gS written as 128-byte row segments.
+    __syncthreads();                                  // both waves are done with the Lp / P tiles: the buffer is reused
+    double* st = shbuf + (size_t)half * (64 * 2 * P1_RT);
+    double* s0t = shbuf + 2 * (64 * 2 * P1_RT) + half * 64;
+    s0t[lane] = s0;
+#pragma unroll
+    for (int c0 = 0; c0 < QH; c0 += 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (c0 + k < QH) {
+          st[lane * (2 * P1_RT) + k] = s1[c0 + k];
+          st[lane * (2 * P1_RT) + P1_RT + k] = s2[c0 + k];
+        }
+      }
+      wave_lds_sync();
+      const int col = c0 + (lane & 15);
+      const bool cok = col < QH;
+      const int cc = cok ? col : QH - 1;
+      const int q = qo + cc;
+      const double il = (q < Q) ? 1.0 / lam[q] : 0.0;
+      double mu[16], e[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = 4 * k + (lane >> 4);
+        const int64_t rr = (n0 + row < N) ? n0 + row : N - 1;
+        mu[k] = Xmu[rr * QP + q];
+        e[k] = e1[rr * QP + q];
+      }
+      double dls = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int row = 4 * k + (lane >> 4);
+        const bool rok = n0 + row < N;
+        const double a1 = st[row * (2 * P1_RT) + (lane & 15)], a2 = st[row * (2 * P1_RT) + P1_RT + (lane & 15)], sr = s0t[row];
+        const double S2 = mu[k] * mu[k] * sr - 2.0 * mu[k] * a1 + a2;
+        if (rok && cok) {
+          gmu[(n0 + row) * QP + q] = -e[k] * (mu[k] * sr - a1);
+          gS[(n0 + row) * QP + q] = 0.5 * e[k] * e[k] * S2 - 0.5 * e[k] * sr;
+        }
+        const double el = e[k] * il;
+        dls += (rok && cok && q < Q) ? (-0.5 * el * el * S2 - 0.5 * sr * (1.0 - el) * il) : 0.0;
+      }
+      dls += __shfl_xor(dls, 16);
+      dls += __shfl_xor(dls, 32);
+      if (lane < 16 && cok) dl_s[q] += dls;          // slot q belongs to this lane of this wave only
+      wave_lds_sync();
+    }
+    if (DY && half == 0 && ok) {
+      const double beta = 1.0 / noise[0];
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) dYm[n * D + d] = -beta * Ym[n * D + d] + dy[d];
+    }
+  }
+  const double ls_tot = block_sum(ls_acc, scratch);
+  __syncthreads();
+  if (t < QP) dlam_part[(size_t)blockIdx.x * QP + t] = dl_s[t];
+  if (t == 0) lsum_part[blockIdx.x] = ls_tot;
+}
+
+bool psi1_svi_supported(int D) { return D >= 1 && D <= 16; }
+int psi1_svi_rows_blocks(int64_t N) {
+  int64_t b = (N + 63) / 64;
+  return (int)(b < 1 ? 1 : (b > PSI1_ROWS_MAXBLK ? PSI1_ROWS_MAXBLK : b));
+}
+
+template <int QP, int DP>
+static void psi1_svi_dispatch(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms& zt, const RowTerms& rt,
+                              const double* Ym, const double* Cpsi1, const double* noise, double* P, double* Lp,
+                              double* psi1Y_part, double* gmu, double* gS, double* dYm, double* dlam_part,
+                              double* lsum_part, double* dz_part, int nblk) {
+  hipLaunchKernelGGL((psi1_svi_fwd_kernel<QP, DP>), dim3(nblk), dim3(256), 0, s, N, M, D, zt.Zc, rt.e1, rt.em, rt.g1, Ym,
+                     Cpsi1, dYm ? P : nullptr, Lp, psi1Y_part);
+  const int rb = psi1_svi_rows_blocks(N);
+  if (dYm)
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, DP, true>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+                       rt.e1, Lp, P, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
+  else
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+                       rt.e1, Lp, Lp, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
+  hipLaunchKernelGGL((psi1_svi_dz_kernel<QP>), dim3(nblk), dim3(256), 0, s, N, M, zt.Zc, rt.e1, rt.em, Lp, dz_part);
+}
+
+// Launches the three passes; the caller reduces psi1Y_part [nblk x D x M], dz_part [nblk x M x QP] and
+// dlam_part / lsum_part [psi1_svi_rows_blocks(N) x QP / x 1].
+void launch_psi1_svi(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms& zt, const RowTerms& rt, const double* Ym,
+                     const double* Cpsi1, const double* noise, double* P, double* Lp, double* psi1Y_part, double* gmu,
+                     double* gS, double* dYm, double* dlam_part, double* lsum_part, double* dz_part, int nblk) {
+#define P1S(qp)                                                                                                       \
+  case qp:                                                                                                            \
+    if (D <= 1) psi1_svi_dispatch<qp, 1>(s, N, M, Q, D, zt, rt, Ym, Cpsi1, noise, P, Lp, psi1Y_part, gmu, gS, dYm, dlam_part, lsum_part, dz_part, nblk); \
+    else if (D <= 4) psi1_svi_dispatch<qp, 4>(s, N, M, Q, D, zt, rt, Ym, Cpsi1, noise, P, Lp, psi1Y_part, gmu, gS, dYm, dlam_part, lsum_part, dz_part, nblk); \
+    else psi1_svi_dispatch<qp, 16>(s, N, M, Q, D, zt, rt, Ym, Cpsi1, noise, P, Lp, psi1Y_part, gmu, gS, dYm, dlam_part, lsum_part, dz_part, nblk); \
+    break;
+  switch (zt.QP) {
+    P1S(8) P1S(16) P1S(24) P1S(32) P1S(40) P1S(48) P1S(56) P1S(64)
+    default: break;
+  }
+#undef P1S
 }
 
 // ------------------------------------------------------------------------------------------------------------------
