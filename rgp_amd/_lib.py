@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librgp_hip.so')
+LIB_PATH = os.environ.get('RGP_HIP_LIB') or os.path.join(_HERE, 'librgp_hip.so')
 
 RGP_OK, RGP_ERR_BAD_ARG, RGP_ERR_HIP, RGP_ERR_NOT_PD, RGP_ERR_WORKSPACE = 0, 1, 2, 3, 4
 RGP_MODE_VARDTC, RGP_MODE_SVI = 0, 1

@@ -566,9 +566,9 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
   L.dz2_part = ws.take<double>((size_t)2 * L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.dlam1_part = ws.take<double>((size_t)PSI1_ROWS_MAXBLK * QP); L.dlam1 = ws.take<double>(QP);     // PSI1_ROWS_MAXBLK >= NBLK1
-  L.dlam2_part = ws.take<double>((size_t)2 * L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);
+  L.dlam2_part = ws.take<double>((size_t)4 * L.nblk2 * QP); L.dlam2 = ws.take<double>(QP);      // up to 8 teams x num_cu
   L.lsum1_part = ws.take<double>(PSI1_ROWS_MAXBLK); L.lsum1 = ws.take<double>(1);
-  L.wsum2_part = ws.take<double>((size_t)2 * L.nblk2); L.wsum2 = ws.take<double>(1);
+  L.wsum2_part = ws.take<double>((size_t)4 * L.nblk2); L.wsum2 = ws.take<double>(1);
   L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
   L.psi1Y_part = ws.take<double>((size_t)L.nblk1 * (D > 0 ? D : 1) * M); L.psi1Y = ws.take<double>((size_t)(D > 0 ? D : 1) * M);
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);

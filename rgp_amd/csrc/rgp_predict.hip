@@ -164,7 +164,7 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   const int QP = round_up(Q, 8);
   // Z-derived terms in the handle's workspace
   rgp_status st;
-  const size_t need = ((size_t)2 * QP + (size_t)M * QP + (size_t)QP * RGP_PSI2_TEAM + 2 * (size_t)M * M) * sizeof(double) + 8 * 256;
+  const size_t need = ((size_t)2 * QP + (size_t)M * QP + (size_t)QP * RGP_PSI2_TEAM + 2 * (size_t)M * M + 2) * sizeof(double) + 9 * 256;
   if ((st = rgp_ensure_ws(h, need))) return st;
   WsAlloc ws(h->ws);
   ZTerms zt{};

@@ -38,6 +38,7 @@ struct WindowSpec {     // implicit lagged windows (rgp_layer_in)
 
 size_t psi2_num_blocks(rgp_handle h, int64_t N);
 bool psi2_use_rows4(int M, int QP);
+int psi2_packed_teams(int M, int QP);     // > 4: packed-team kernel with that many rows in flight per workgroup
 // grid size and number of per-workgroup partial slabs each psi2 launch produces
 struct Psi2Plan { int grid, n_p2, n_dz, n_dl; };
 Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd);      // fused pass with four teams per workgroup and the dZ accumulator in LDS

@@ -13,6 +13,7 @@
 #include "rgp_psi.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1166,6 +1167,313 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 }
 #undef zrow
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused forward + backward pass with PACKED teams, for 64 <= M <= 102: the 512 threads of a workgroup are split into
+// NT = 512 / M teams of exactly M threads (M = 100: 5 rows in flight, 500 of 512 lanes busy instead of 400), so a wave
+// holds lanes of up to two data rows.  What keeps that cheap:
+//   * all threads sweep m' in the same order, so z[m',:] stays a scalar operand for mixed waves too;
+//   * the forward sums are LDS fp64 atomics (ds_add_f64) from all teams, no rotation and no barriers inside the sweep.
+//     The NT adds a slot receives per iteration arrive in hardware order, so the last bits of psi2 can differ from run to
+//     run; rgp_set_deterministic (or RGP_PSI2_NO_PACKED=1) selects the rotating four-team kernel instead, which is
+//     bit-reproducible.  (A 64-bit fixed-point accumulator was order independent but kept only ~9 digits on entries far
+//     below the row bound; it failed the 1e-10 gradient parity on strongly cancelling cases.)
+//   * the dZ slab is updated by one team after the other (NT short phases);
+//   * the per-row reductions over m split each wave's transposed sum at the team boundary.
+// ------------------------------------------------------------------------------------------------------------------
+#define PSI2_MAX_NT 8
+
+// DPP lane exchange of a double (two 32-bit moves); CTRL is a gfx9 dpp_ctrl value.
+template <int CTRL>
+static __device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of 8 lanes, result in every lane of the group (no LDS round trips)
+static __device__ __forceinline__ double sum8_dpp(double x) {
+  x += dpp_f64<0xB1>(x);            // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);            // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);           // row_half_mirror
+  return x;
+}
+// sum over the wave, result in every lane; fixed order
+static __device__ __forceinline__ double wave_sum_dpp(double x) {
+  x = sum8_dpp(x);
+  x += dpp_f64<0x140>(x);           // row_mirror: rows of 16 complete
+  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
+template <int QP>
+static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
+                                                     double& v, const double base, const double hbm, const double dlv,
+                                                     double* __restrict__ p2slot, const bool own) {
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; q += 4) {
+    c0 += dzl[q] * zs[q];
+    c1 += dzl[q + 1] * zs[q + 1];
+    c2 += dzl[q + 2] * zs[q + 2];
+    c3 += dzl[q + 3] * zs[q + 3];
+  }
+  const double E = (base + hbm) - 0.5 * ((c0 + c1) + (c2 + c3));
+  const double p = exp(E);
+  if (own) atomicAdd(p2slot, p);          // ds_add_f64, no return
+  const double w = p * dlv;
+  v += w;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) y[q] += w * zs[q];
+}
+
+#ifdef PSI2_STAMPS
+#define STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define STAMP(acc) do { } while (0)
+#endif
+
+template <int QP>
+__global__ void __launch_bounds__(PSI2_T4, 2)
+psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const double* __restrict__ Zc,
+                  const double* __restrict__ lam_g, const double* __restrict__ dLs_g, const double* __restrict__ Xmu_g,
+                  const double* __restrict__ d2_g, const double* __restrict__ g0_g,
+                  double* __restrict__ p2_part, double* __restrict__ dz_part, double* __restrict__ dlam_part,
+                  double* __restrict__ wsum_part, double* __restrict__ gmu_g, double* __restrict__ gS_g,
+                  const int accumulate, double* dbgout) {
+  extern __shared__ double lds[];
+  const int tri = M * (M + 1) / 2;
+  constexpr int RW = 2 * QP + 8;
+  constexpr int RD = 2 * QP + 2;                          // staged row: d2[QP] | mu[QP] | g0 | pad
+  double* p2acc = lds;                                    // [tri]
+  double* dzacc = lds + tri;                              // [QP x 128]
+  double* hbuf = dzacc + QP * RGP_PSI2_TEAM;              // [NT x 128]
+  double* rowd = hbuf + PSI2_MAX_NT * RGP_PSI2_TEAM;      // [NT x RD]
+  double* red = rowd + PSI2_MAX_NT * RD;                  // [8 waves x RED_WAVE]
+  double* res = red + 8 * RED_WAVE;                       // [8 waves x 2 x RW]
+#ifdef PSI2_STAMPS
+  long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, tG = 0, tH = 0, t0 = 0, t1;
+#endif
+
+  const int t = threadIdx.x;
+  const int wave = t >> 6, lane = t & 63;
+  const int team_raw = t / M;
+  const bool act = team_raw < NT;                         // the last 512 - NT*M threads idle
+  const int team = act ? team_raw : NT - 1;
+  const int tr = act ? t - team_raw * M : M - 1;
+  const double* __restrict__ zrowp = Zc + (size_t)tr * QP;
+#define zrow(q) zrowp[q]
+  double* hb = hbuf + team * RGP_PSI2_TEAM;
+  const double* rd = rowd + team * RD;
+  // team boundary inside this wave: lanes < bnd belong to team ta, the others to ta + 1
+  const int ta = (64 * wave) / M;
+  const int bnd = __builtin_amdgcn_readfirstlane(((ta + 1) * M - 64 * wave < 64) ? (ta + 1) * M - 64 * wave : 64);
+  const bool inA = lane < bnd;
+
+  for (int i = t; i < tri; i += PSI2_T4) p2acc[i] = 0.0;
+  for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) dzacc[i] = 0.0;
+  double ellq = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) ellq += 0.25 * lam_g[q] * zrow(q) * zrow(q);
+  double dlam_acc = 0.0, wsum_acc = 0.0;
+  long long iters = 0;
+
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + NT - 1) / NT * NT;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  const double* __restrict__ dlrow = dLs_g + tr;
+
+  // staged row element of this thread (one per thread: NT*RD <= 512): loaded one iteration ahead
+  const int sk = t / RD, sj = t - sk * RD;
+  const bool stager = t < NT * RD;
+  auto stage_load = [&](int64_t rr) -> double {
+    if (!stager) return 0.0;
+    const int64_t nk = (rr + sk < r1) ? rr + sk : r1 - 1;
+    if (nk < 0) return 0.0;
+    if (sj < QP) return d2_g[nk * QP + sj];
+    if (sj < 2 * QP) return Xmu_g[nk * QP + (sj - QP)];
+    if (sj == 2 * QP) return g0_g[nk];
+    return 0.0;
+  };
+  double staged = (r0 < r1) ? stage_load(r0) : 0.0;
+  if (stager) rowd[t] = staged;
+  __syncthreads();
+
+  for (int64_t rr = r0; rr < r1; rr += NT) {
+    asm volatile("" ::: "memory");
+    ++iters;
+#ifdef PSI2_STAMPS
+    t0 = __builtin_readcyclecounter();
+#endif
+    const bool valid = rr + team < r1;
+    const int64_t n = valid ? rr + team : r1 - 1;
+    // loads whose latency hides under the sweep: next iteration's rows, and this row's gradient slots
+    staged = (rr + NT < r1) ? stage_load(rr + NT) : 0.0;
+    const bool grad_thread = act && tr < QP && valid;
+    double g_old_mu = 0.0, g_old_S = 0.0;
+    if (grad_thread && accumulate && tr < Q) {
+      g_old_mu = gmu_g[n * QP + tr];
+      g_old_S = gS_g[n * QP + tr];
+    }
+    STAMP(tA);
+    double dzl[QP];
+    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; q += 2) {
+      const double z0 = zrow(q), z1 = zrow(q + 1);
+      const double d0 = rd[q], d1 = rd[q + 1];
+      dzl[q] = z0 * (d0 - lam_g[q]);
+      dzl[q + 1] = z1 * (d1 - lam_g[q + 1]);
+      h0 += z0 * d0 * (rd[QP + q] - 0.25 * z0);
+      h1 += z1 * d1 * (rd[QP + q + 1] - 0.25 * z1);
+    }
+    const double h = (h0 + h1) - ellq;
+    if (act) hb[tr] = h;
+    const double base = (act && valid) ? (rd[2 * QP] + h) : -INFINITY;
+    __syncthreads();
+    STAMP(tB);
+
+    double y[QP];
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = 0.0;
+    {
+      const int last = M - 1;
+      double dlA = dlrow[0];
+      double dlB = dlrow[(size_t)((1 < M) ? 1 : last) * M];
+      for (int mp = 0; mp < M; mp += 2) {
+        const int mpa = mp, mpb = (mp + 1 < M) ? mp + 1 : last;
+        const double dla = dlA, dlb = dlB;
+        dlA = dlrow[(size_t)((mp + 2 < M) ? mp + 2 : last) * M];
+        dlB = dlrow[(size_t)((mp + 3 < M) ? mp + 3 : last) * M];
+        psi2_pair_fix<QP>(Zc + (size_t)mpa * QP, dzl, y, v, base, hb[mpa], dla, p2acc + (mpa * (mpa + 1) / 2 + tr),
+                          act && mpa >= tr);
+        if (mp + 1 < M)
+          psi2_pair_fix<QP>(Zc + (size_t)mpb * QP, dzl, y, v, base, hb[mpb], dlb, p2acc + (mpb * (mpb + 1) / 2 + tr),
+                            act && mpb >= tr);
+      }
+    }
+
+    asm volatile("" ::: "memory");
+    STAMP(tC);
+    // per-wave reductions over m, split at the team boundary: slot 0 = lanes < bnd (team ta), slot 1 = the rest.
+    // LDS executes one wave's instructions in order, so the transposing write -> read needs no wait in between; the
+    // 8-lane partial sums are finished with DPP moves (no ds_bpermute round trips).
+    double* wres = res + (size_t)wave * 2 * RW;
+    {
+      double* wred = red + wave * RED_WAVE;
+      const double wsA = wave_sum_dpp(inA ? v : 0.0);
+      const double wsB = (bnd < 64) ? wave_sum_dpp(inA ? 0.0 : v) : 0.0;
+      if (lane == 0) { wres[2 * QP] = wsA; wres[RW + 2 * QP] = wsB; }
+      const int jv = lane >> 3, part = lane & 7;
+#pragma unroll
+      for (int q0 = 0; q0 < QP; q0 += RED_QC) {
+#pragma unroll
+        for (int j = 0; j < RED_QC; ++j) {
+          const double z = zrow(q0 + j);
+          wred[j * RED_RS + lane] = v * z;
+          wred[(RED_QC + j) * RED_RS + lane] = 0.5 * z * (v * z + y[q0 + j]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = wred[jv * RED_RS + part + 8 * k];
+        __builtin_amdgcn_wave_barrier();
+        double sA = 0.0, sB = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const bool a = part + 8 * k < bnd;
+          sA += a ? x[k] : 0.0;
+          sB += a ? 0.0 : x[k];
+        }
+        sA = sum8_dpp(sA);
+        if (bnd < 64) sB = sum8_dpp(sB);
+        if (part == 0) {
+          const int o = (jv < RED_QC ? 0 : QP) + q0 + (jv % RED_QC);
+          wres[o] = sA;
+          wres[RW + o] = sB;
+        }
+      }
+    }
+#ifdef PSI2_STAMPS
+    STAMP(tD);
+    __syncthreads();
+    STAMP(tG);
+#endif
+    // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab: one team after the other (fixed order), each as one
+    // batch of loads, adds and stores
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = rd[q] * (v * (2.0 * rd[QP + q] - zrow(q)) - y[q]);
+    STAMP(tH);
+    for (int k = 0; k < NT; ++k) {
+      if (act && team_raw == k) {
+        double tmp[QP];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) tmp[q] = dzacc[q * RGP_PSI2_TEAM + tr];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) dzacc[q * RGP_PSI2_TEAM + tr] = tmp[q] + y[q];
+      }
+      __syncthreads();
+    }
+    STAMP(tE);
+    // row gradients: thread (team, q) combines the wave partials that cover its team, in wave order
+    if (grad_thread) {
+      const int q = tr;
+      if (q < Q) {
+        const int w0 = (team * M) >> 6, w1 = (team * M + M - 1) >> 6;
+        double w = 0.0, a1 = 0.0, a23 = 0.0;
+        for (int wv = w0; wv <= w1; ++wv) {
+          const int slot = ((64 * wv) / M == team) ? 0 : 1;
+          const double* tres = res + ((size_t)wv * 2 + slot) * RW;
+          w += tres[2 * QP];
+          a1 += tres[q];
+          a23 += tres[QP + q];
+        }
+        const double mu = rd[QP + q], dq = rd[q];
+        const double dmu = 2.0 * dq * (a1 - mu * w);
+        const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
+        const double dS = -2.0 * dq * dq * dd;
+        gmu_g[n * QP + q] = g_old_mu + dmu;
+        gS_g[n * QP + q] = g_old_S + dS;
+        const double il = 1.0 / lam_g[q];
+        dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
+        if (q == 0) wsum_acc += w;
+      } else if (!accumulate) {
+        gmu_g[n * QP + q] = 0.0;
+        gS_g[n * QP + q] = 0.0;
+      }
+    }
+    __syncthreads();                                  // everyone is done with rowd / res / hbuf of this iteration
+    if (stager) rowd[t] = staged;
+    __syncthreads();
+    STAMP(tF);
+  }
+#ifdef PSI2_STAMPS
+  if (dbgout && t == 0) { double* o = dbgout + blockIdx.x * 8; o[0] = tA; o[1] = tB; o[2] = tC; o[3] = tD; o[4] = tE; o[5] = tF; o[6] = (double)iters; o[7] = tG; dbgout[256 * 8 + blockIdx.x] = tH; }
+#endif
+
+  {
+    double* out = p2_part + (size_t)blockIdx.x * tri;
+    for (int i = t; i < tri; i += PSI2_T4) out[i] = p2acc[i];
+    double* outz = dz_part + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM;
+    for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) outz[i] = dzacc[i];
+  }
+  if (act && tr < QP) dlam_part[((size_t)blockIdx.x * NT + team) * QP + tr] = (tr < Q) ? dlam_acc : 0.0;
+  if (act && tr == 0) wsum_part[(size_t)blockIdx.x * NT + team] = wsum_acc;
+}
+#undef zrow
+
+static size_t psi2_rowsN_lds(int M, int QP) {
+  const size_t tri = (size_t)M * (M + 1) / 2;
+  return (tri + (size_t)QP * RGP_PSI2_TEAM + PSI2_MAX_NT * RGP_PSI2_TEAM + PSI2_MAX_NT * (2 * (size_t)QP + 2) +
+          8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8)) * sizeof(double);
+}
+
+// number of packed teams (0: use the four-team / two-team kernels)
+int psi2_packed_teams(int M, int QP) {
+  static const bool off = getenv("RGP_PSI2_NO_PACKED") != nullptr;
+  if (off || M < 64 || M > 102) return 0;
+  if (psi2_rowsN_lds(M, QP) > 160 * 1024) return 0;
+  return PSI2_T4 / M;
+}
+
 // LDS bytes of the four-team kernel
 static size_t psi2_rows4_lds(int M, int QP) {
   const size_t tri = (size_t)M * (M + 1) / 2;
@@ -1179,7 +1487,13 @@ bool psi2_use_rows4(int M, int QP) {
 
 Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   Psi2Plan pl;
-  if (fwd && bwd && psi2_use_rows4(M, QP)) {
+  const int nt = (fwd && bwd) ? psi2_packed_teams(M, QP) : 0;
+  if (nt > 4) {
+    int64_t g = h->num_cu;                         // one 512-thread workgroup per CU, nt rows in flight
+    if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
+    pl.grid = (int)(g < 1 ? 1 : g);
+    pl.n_p2 = pl.grid; pl.n_dz = pl.grid; pl.n_dl = nt * pl.grid;
+  } else if (fwd && bwd && psi2_use_rows4(M, QP)) {
     int64_t g = h->num_cu;                         // one 512-thread workgroup per CU
     if (g > (N + 3) / 4) g = (N + 3) / 4;
     pl.grid = (int)(g < 1 ? 1 : g);
@@ -1214,6 +1528,28 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
                        a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part,        \
                        a.o.gmu, a.o.gS, a.o.accumulate);                                                              \
   } while (0)
+  const int nt = (fwd && bwd) ? psi2_packed_teams(a.M, QP) : 0;
+  if (nt > 4) {
+    const size_t ln = psi2_rowsN_lds(a.M, QP);
+    static double* dbgbuf = nullptr;
+    if (!dbgbuf && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf, 256 * 9 * sizeof(double));
+    hipError_t e = hipFuncSetAttribute((const void*)psi2_rowsN_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((psi2_rowsN_kernel<QP>), dim3(nblk), dim3(PSI2_T4), ln, s, a.N, a.M, a.Q, nt, a.Zc, a.lam, a.dLs, a.Xmu,
+                       a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
+                       a.o.accumulate, dbgbuf);
+    if (dbgbuf) {
+      (void)hipStreamSynchronize(s);
+      static double hb[256 * 9];
+      (void)hipMemcpy(hb, dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
+      double a[7] = {0};
+      for (int b = 0; b < nblk; ++b) for (int k = 0; k < 7; ++k) a[k] += hb[b * 8 + k] / nblk;
+      double th = 0; for (int b = 0; b < nblk; ++b) th += hb[256 * 8 + b] / nblk;
+      fprintf(stderr, "psi2N QP=%d iters=%.0f cycles/iter: stage %.0f prologue %.0f sweep %.0f red %.0f imbalance %.0f ycalc %.0f dzphases %.0f rowgrad %.0f\n", QP, a[6],
+              a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], hb[7] / a[6], th / a[6], a[4] / a[6], a[5] / a[6]);
+    }
+    return hipSuccess;
+  }
   if (fwd && bwd && psi2_use_rows4(a.M, QP)) {
     const size_t l4 = psi2_rows4_lds(a.M, QP);
     hipError_t e = hipFuncSetAttribute((const void*)psi2_rows4_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4);

@@ -64,8 +64,9 @@ def test_psi_backward(H, N, M, Q, nctrl):
     ref = ps.PsiStatsFast(64).grads(var, il, Z, mu, S, w0, w1, w2)
     g = H.psi_backward(dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il), w0.sum(), dev(H, w1), dev(H, w2))
     H.sync()
+    tol = 1e-10
     for k in ('dvar', 'dinv_l', 'dZ', 'dmu', 'dS'):
-        assert rel(g[k].cpu().numpy().reshape(np.shape(ref[k])), ref[k]) < 1e-10, k
+        assert rel(g[k].cpu().numpy().reshape(np.shape(ref[k])), ref[k]) < tol, k
     # psi1-only and psi2-only paths
     ref1 = ps.PsiStatsFast(64).grads(var, il, Z, mu, S, 0 * w0, w1, None)
     g1 = H.psi_backward(dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il), 0.0, dev(H, w1), None)
@@ -74,7 +75,7 @@ def test_psi_backward(H, N, M, Q, nctrl):
     H.sync()
     for k in ('dvar', 'dinv_l', 'dZ', 'dmu', 'dS'):
         assert rel(g1[k].cpu().numpy().reshape(np.shape(ref1[k])), ref1[k]) < 1e-10, k
-        assert rel(g2[k].cpu().numpy().reshape(np.shape(ref2[k])), ref2[k]) < 1e-10, k
+        assert rel(g2[k].cpu().numpy().reshape(np.shape(ref2[k])), ref2[k]) < tol, k
 
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'inference_*.npz')))
