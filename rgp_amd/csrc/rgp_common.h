@@ -51,6 +51,7 @@ struct rgp_ctx {
   int prepared_head = 0, prepared_count = 0;   // FIFO of slots prepared by rgp_layer_prepare
   int prepared_slot[NSLOT] = {0, 0, 0, 0};
   bool overlap = true;
+  bool deterministic = false;       // rgp_set_deterministic: fixed-order psi2 kernels only
   hipStream_t side_pre = nullptr, side_post = nullptr;
   hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
   hipEvent_t ev_pre[NSLOT] = {nullptr, nullptr, nullptr, nullptr};

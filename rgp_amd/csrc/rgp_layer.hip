@@ -107,6 +107,12 @@ extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
   return RGP_OK;
 }
 
+extern "C" rgp_status rgp_set_deterministic(rgp_handle h, int on) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  h->deterministic = on != 0;
+  return RGP_OK;
+}
+
 extern "C" rgp_status rgp_set_profiling(rgp_handle h, int on) {
   if (!h) return RGP_ERR_BAD_ARG;
   h->profiling = on != 0;

@@ -1487,7 +1487,7 @@ bool psi2_use_rows4(int M, int QP) {
 
 Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   Psi2Plan pl;
-  const int nt = (fwd && bwd) ? psi2_packed_teams(M, QP) : 0;
+  const int nt = (fwd && bwd && !h->deterministic) ? psi2_packed_teams(M, QP) : 0;
   if (nt > 4) {
     int64_t g = h->num_cu;                         // one 512-thread workgroup per CU, nt rows in flight
     if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
@@ -1513,7 +1513,7 @@ size_t psi2_num_blocks(rgp_handle h, int64_t N) {
 }
 
 template <int QP>
-static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Args& a, int nblk) {
+static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Args& a, int nblk, bool packed_ok) {
   const int tri = a.M * (a.M + 1) / 2;
   size_t lds = (size_t)2 * RGP_PSI2_TEAM;
   if (fwd) lds += tri + RGP_PSI2_TEAM;
@@ -1528,7 +1528,7 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
                        a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part,        \
                        a.o.gmu, a.o.gS, a.o.accumulate);                                                              \
   } while (0)
-  const int nt = (fwd && bwd) ? psi2_packed_teams(a.M, QP) : 0;
+  const int nt = (fwd && bwd && packed_ok) ? psi2_packed_teams(a.M, QP) : 0;
   if (nt > 4) {
     const size_t ln = psi2_rowsN_lds(a.M, QP);
     static double* dbgbuf = nullptr;
@@ -1575,14 +1575,14 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
   hipStream_t s = h->stream;
   hipError_t e = hipSuccess;
   switch (zt.QP) {
-    case 8:  e = psi2_dispatch<8>(s, fwd, bwd, a, nblk); break;
-    case 16: e = psi2_dispatch<16>(s, fwd, bwd, a, nblk); break;
-    case 24: e = psi2_dispatch<24>(s, fwd, bwd, a, nblk); break;
-    case 32: e = psi2_dispatch<32>(s, fwd, bwd, a, nblk); break;
-    case 40: e = psi2_dispatch<40>(s, fwd, bwd, a, nblk); break;
-    case 48: e = psi2_dispatch<48>(s, fwd, bwd, a, nblk); break;
-    case 56: e = psi2_dispatch<56>(s, fwd, bwd, a, nblk); break;
-    case 64: e = psi2_dispatch<64>(s, fwd, bwd, a, nblk); break;
+    case 8:  e = psi2_dispatch<8>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 16: e = psi2_dispatch<16>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 24: e = psi2_dispatch<24>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 32: e = psi2_dispatch<32>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 40: e = psi2_dispatch<40>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 48: e = psi2_dispatch<48>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 56: e = psi2_dispatch<56>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 64: e = psi2_dispatch<64>(s, fwd, bwd, a, nblk, !h->deterministic); break;
     default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: unsupported padded Q");
   }
   if (e == hipSuccess) e = hipGetLastError();

@@ -341,3 +341,23 @@ def test_unsupported_sizes_fail_loudly():
     m2 = DeepAutoreg([0, 40], Y[:1], U=U[:1], U_win=30, nDims=[1, 1], num_inducing=4, inference_method='svi')   # Q = 70 > 64
     with pytest.raises(RgpError):
         m2.evaluate()
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """rgp_set_deterministic(1): the rotating-team psi2 kernel adds in a fixed order, so two evaluations agree bit for bit;
+    the default packed-team kernel (fp64 LDS atomics in hardware order) agrees with it to rounding."""
+    import torch
+    o, g = build_pair(n_seq=4, T=300, wins=(0, 6, 6), nDims=(3, 1, 1), M=100, U_win=6, u_dim=1, y_dim=3, seed=9)
+    g.handle.set_deterministic(True)
+    try:
+        e1 = float(g.evaluate().item()); g.handle.sync()
+        G1 = g.grad_array.clone()
+        e2 = float(g.evaluate().item()); g.handle.sync()
+        G2 = g.grad_array.clone()
+        assert e1 == e2 and torch.equal(G1, G2)
+    finally:
+        g.handle.set_deterministic(False)
+    e3 = float(g.evaluate().item()); g.handle.sync()
+    G3 = g.grad_array.clone()
+    assert abs(e3 - e1) <= 1e-12 * abs(e1)
+    assert float((G3 - G1).abs().max()) <= 1e-10 * float(G1.abs().max())
