@@ -22,6 +22,27 @@ static __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// DPP lane exchange of a double (two 32-bit moves); CTRL is a gfx9 dpp_ctrl value.
+template <int CTRL>
+static __device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned groups of 8 lanes, result in every lane of the group (no LDS round trips)
+static __device__ __forceinline__ double sum8_dpp(double x) {
+  x += dpp_f64<0xB1>(x);            // quad_perm [1,0,3,2]
+  x += dpp_f64<0x4E>(x);            // quad_perm [2,3,0,1]
+  x += dpp_f64<0x141>(x);           // row_half_mirror
+  return x;
+}
+// sum over the wave, result in every lane; fixed order
+static __device__ __forceinline__ double wave_sum_dpp(double x) {
+  x = sum8_dpp(x);
+  x += dpp_f64<0x140>(x);           // row_mirror: rows of 16 complete
+  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
 // Sum over the whole workgroup; result valid in every thread. `scratch` holds >= 16 doubles of LDS.
 static __device__ __forceinline__ double block_sum(double v, double* scratch) {
   v = wave_sum(v);

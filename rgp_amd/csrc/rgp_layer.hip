@@ -873,6 +873,28 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
 // ==================================================================================================================
 // Takes the next workspace slot, computes the Z terms on the main stream and starts the data-independent part of the
 // SVI chain on the side stream.  ev_pre[slot] fires when Cpsi1 / dL_dpsi2 / the factors are ready.
+static WindowSpec svi_window_spec(const rgp_layer_in* in, const LayerWs& L) {
+  WindowSpec w{};
+  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = in->D;
+  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
+  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
+  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+  return w;
+}
+
+static rgp_status svi_check_args(rgp_handle h, const rgp_layer_in* in) {
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  rgp_status st = check_geometry(h, in->N, in->M, Q);
+  if (st) return st;
+  if (in->y_uncertain && (in->X_dim != in->D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
+  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
+  if (in->D > 64 * CM_MAXK) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large");
+  return RGP_OK;
+}
+
+// Everything of a layer step that depends only on the parameters and the signals, not on the M x M chain: K_uu and the
+// chain's first stage (side stream), the window tables and the row terms (main stream).  rgp_layer_prepare issues this for
+// every layer before the first step, so the main stream has row work to do while the first chain runs.
 static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* slot_out) {
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
@@ -898,6 +920,13 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   }
   if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
   if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
+  // tables + rows
+  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
+  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
+  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  const WindowSpec w = svi_window_spec(in, L);
+  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
   *slot_out = slot;
   return RGP_OK;
 }
@@ -917,8 +946,7 @@ extern "C" rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, co
 extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
   if (!h || !in) return RGP_ERR_BAD_ARG;
   if (in->mode != RGP_MODE_SVI) return RGP_OK;
-  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
-  rgp_status st = check_geometry(h, in->N, in->M, Q);
+  rgp_status st = svi_check_args(h, in);
   if (st) return st;
   if (h->prepared_count >= rgp_ctx::NSLOT - 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_prepare: too many layers outstanding");
   int slot;
@@ -935,11 +963,8 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
-  rgp_status st = check_geometry(h, N, M, Q);
+  rgp_status st = svi_check_args(h, in);
   if (st) return st;
-  if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
-  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
-  if (D > 64 * CM_MAXK) return rgp_fail(h, RGP_ERR_BAD_ARG, "D too large");
   LayerWs L;
   SviChain c{};
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
@@ -958,17 +983,8 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
   const int QP = L.zt.QP;
 
-  // tables + rows
-  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
-  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
-  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
-  WindowSpec w{};
-  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
-  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
-  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
-  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
-  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
-  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+  // the window tables and row terms were produced by svi_prepare_slot (main stream)
+  WindowSpec w = svi_window_spec(in, L);
 
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;

@@ -102,20 +102,36 @@ __global__ void __launch_bounds__(256) rowprep_kernel(RowPrepArgs a) {
   const double logvar = log(a.variance[0]);
   const bool dense = a.mu != nullptr;
   double yry = 0.0;
-  for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.N; r += (int64_t)gridDim.x * wpb) {
-    int s = 0;
+  // each wave takes a contiguous range of rows: the sequence lookup is one binary search plus increments
+  const int64_t nwaves = (int64_t)gridDim.x * wpb;
+  const int64_t rpw = (a.N + nwaves - 1) / nwaves;
+  const int64_t rbeg = ((int64_t)blockIdx.x * wpb + wave) * rpw;
+  const int64_t rend = (rbeg + rpw < a.N) ? rbeg + rpw : a.N;
+  int s = 0;
+  int64_t seq_end = 0, seq_beg = 0, Ns = 0, own_off_s = 0, up_base_s = 0;
+  if (!dense && rbeg < rend) {
+    int lo = 0, hi = a.w.n_seq;                      // largest s with row_off[s] <= rbeg
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.w.row_off[mid] <= rbeg) lo = mid; else hi = mid;
+    }
+    s = lo - 1;                                      // the loop below advances into sequence lo
+    seq_end = a.w.row_off[lo];
+  }
+  for (int64_t r = rbeg; r < rend; ++r) {
     int64_t nloc = r, own_base = 0, up_base = 0;
     if (!dense) {
-      int lo = 0, hi = a.w.n_seq;                    // largest s with row_off[s] <= r
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.w.row_off[mid] <= r) lo = mid; else hi = mid;
+      while (r >= seq_end) {                         // next non-empty sequence
+        ++s;
+        seq_beg = a.w.row_off[s];
+        seq_end = a.w.row_off[s + 1];
+        Ns = a.w.own_len[s] - a.w.X_win;
+        own_off_s = a.w.own_off[s];
+        up_base_s = (a.w.U_win > 0) ? a.w.up_off[s] + (a.w.up_len[s] - Ns - a.w.U_win + 1) * a.w.U_dim : 0;
       }
-      s = lo;
-      nloc = r - a.w.row_off[s];
-      const int64_t Ns = a.w.own_len[s] - a.w.X_win;
-      own_base = a.w.own_off[s] + nloc * a.w.X_dim;                           // element where the own window starts
-      if (a.w.U_win > 0) up_base = a.w.up_off[s] + ((a.w.up_len[s] - Ns - a.w.U_win + 1) + nloc) * a.w.U_dim;
+      nloc = r - seq_beg;
+      own_base = own_off_s + nloc * a.w.X_dim;                                // element where the own window starts
+      up_base = up_base_s + nloc * a.w.U_dim;
     }
     const int Qx = dense ? 0 : a.w.X_win * a.w.X_dim;
     double sl2 = 0.0, sl1 = 0.0, sdm = 0.0, sem = 0.0;
@@ -149,13 +165,13 @@ __global__ void __launch_bounds__(256) rowprep_kernel(RowPrepArgs a) {
       a.e1[r * a.QP + q] = e1;
       a.em[r * a.QP + q] = e1 * mu;
     }
-    sl2 = wave_sum(sl2); sl1 = wave_sum(sl1); sdm = wave_sum(sdm); sem = wave_sum(sem);
+    sl2 = wave_sum_dpp(sl2); sl1 = wave_sum_dpp(sl1); sdm = wave_sum_dpp(sdm); sem = wave_sum_dpp(sem);
     if (lane == 0) {
       a.g0[r] = 2.0 * logvar - 0.5 * sl2 - sdm;
       a.g1[r] = logvar - 0.5 * sl1 - 0.5 * sem;          // includes -1/2 sum e mu^2 (the psi1 exponent is expanded)
     }
     if (!dense && a.Ym) {                              // outputs of this row: own[X_win + n]
-      const int64_t ybase = a.w.own_off[s] + (a.w.X_win + nloc) * a.w.D;
+      const int64_t ybase = own_off_s + (a.w.X_win + nloc) * a.w.D;
       for (int d = lane; d < a.w.D; d += 64) {
         const double m = a.w.own_mean[ybase + d];
         a.Ym[r * a.w.D + d] = m;
@@ -1181,27 +1197,6 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 //   * the per-row reductions over m split each wave's transposed sum at the team boundary.
 // ------------------------------------------------------------------------------------------------------------------
 #define PSI2_MAX_NT 8
-
-// DPP lane exchange of a double (two 32-bit moves); CTRL is a gfx9 dpp_ctrl value.
-template <int CTRL>
-static __device__ __forceinline__ double dpp_f64(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-// sum over aligned groups of 8 lanes, result in every lane of the group (no LDS round trips)
-static __device__ __forceinline__ double sum8_dpp(double x) {
-  x += dpp_f64<0xB1>(x);            // quad_perm [1,0,3,2]
-  x += dpp_f64<0x4E>(x);            // quad_perm [2,3,0,1]
-  x += dpp_f64<0x141>(x);           // row_half_mirror
-  return x;
-}
-// sum over the wave, result in every lane; fixed order
-static __device__ __forceinline__ double wave_sum_dpp(double x) {
-  x = sum8_dpp(x);
-  x += dpp_f64<0x140>(x);           // row_mirror: rows of 16 complete
-  return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
-}
 
 template <int QP>
 static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
