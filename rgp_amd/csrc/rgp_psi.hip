@@ -1198,10 +1198,38 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 // ------------------------------------------------------------------------------------------------------------------
 #define PSI2_MAX_NT 8
 
+// exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
+// n = rint(x * 64/ln2) = 64 k + j, r = x - n ln2/64 (|r| <= ln2/128) and q the degree-5 Taylor polynomial of expm1 (next term
+// r^6/720 < 4e-17).  T[j] = 2^(j/64) is a 64-entry LDS table.  15 VALU instructions and one LDS read instead of the ~36
+// (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp (the
+// rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register sources:
+// the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
+#define PSI2_EXP_TAB 64
+static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
+  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
+  const double t = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);          // 64/ln2; integer n in the low mantissa bits
+  const int n = __double2loint(t);
+  const double nf = t - 0x1.8p52;
+  double r = fma(nf, -0x1.62e42fefa0000p-7, x);                     // ln2/64 split: high part has 33 significant bits
+  r = fma(nf, -0x1.cf79abc9e3b3ap-46, r);
+  const double tj = T[n & (PSI2_EXP_TAB - 1)];
+  double q = fma_rrr(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);      // 1/120, 1/24
+  q = fma_rrr(q, r, 0x1.5555555555555p-3);                                 // 1/6
+  q = fma_rrr(q, r, 0.5);
+  q = fma_rrr(q, r, 1.0);
+  q = q * r;
+  return ldexp(fma(tj, q, tj), n >> 6);
+}
+
 template <int QP>
 static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
                                                      double& v, const double base, const double hbm, const double dlv,
-                                                     double* __restrict__ p2slot, const bool own) {
+                                                     double* __restrict__ p2slot, const bool own, const double* __restrict__ etab) {
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
 #pragma unroll
   for (int q = 0; q < QP; q += 4) {
@@ -1211,7 +1239,7 @@ static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ 
     c3 += dzl[q + 3] * zs[q + 3];
   }
   const double E = (base + hbm) - 0.5 * ((c0 + c1) + (c2 + c3));
-  const double p = exp(E);
+  const double p = exp_tab(E, etab);
   if (own) atomicAdd(p2slot, p);          // ds_add_f64, no return
   const double w = p * dlv;
   v += w;
@@ -1243,6 +1271,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
   double* rowd = hbuf + PSI2_MAX_NT * RGP_PSI2_TEAM;      // [NT x RD]
   double* red = rowd + PSI2_MAX_NT * RD;                  // [8 waves x RED_WAVE]
   double* res = red + 8 * RED_WAVE;                       // [8 waves x 2 x RW]
+  double* etab = res + 8 * 2 * RW;                        // [64] 2^(j/64)
 #ifdef PSI2_STAMPS
   long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, tG = 0, tH = 0, t0 = 0, t1;
 #endif
@@ -1264,6 +1293,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
 
   for (int i = t; i < tri; i += PSI2_T4) p2acc[i] = 0.0;
   for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) dzacc[i] = 0.0;
+  if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
   double ellq = 0.0;
 #pragma unroll
   for (int q = 0; q < QP; ++q) ellq += 0.25 * lam_g[q] * zrow(q) * zrow(q);
@@ -1274,6 +1304,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
   const int64_t r0 = (int64_t)blockIdx.x * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
   const double* __restrict__ dlrow = dLs_g + tr;
+  const int tr_own = act ? tr : 0x7fffffff;          // inactive threads own no slot
 
   // staged row element of this thread (one per thread: NT*RD <= 512): loaded one iteration ahead
   const int sk = t / RD, sj = t - sk * RD;
@@ -1339,10 +1370,10 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
         dlA = dlrow[(size_t)((mp + 2 < M) ? mp + 2 : last) * M];
         dlB = dlrow[(size_t)((mp + 3 < M) ? mp + 3 : last) * M];
         psi2_pair_fix<QP>(Zc + (size_t)mpa * QP, dzl, y, v, base, hb[mpa], dla, p2acc + (mpa * (mpa + 1) / 2 + tr),
-                          act && mpa >= tr);
+                          mpa >= tr_own, etab);
         if (mp + 1 < M)
           psi2_pair_fix<QP>(Zc + (size_t)mpb * QP, dzl, y, v, base, hb[mpb], dlb, p2acc + (mpb * (mpb + 1) / 2 + tr),
-                            act && mpb >= tr);
+                            mpb >= tr_own, etab);
       }
     }
 
@@ -1458,7 +1489,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
 static size_t psi2_rowsN_lds(int M, int QP) {
   const size_t tri = (size_t)M * (M + 1) / 2;
   return (tri + (size_t)QP * RGP_PSI2_TEAM + PSI2_MAX_NT * RGP_PSI2_TEAM + PSI2_MAX_NT * (2 * (size_t)QP + 2) +
-          8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8)) * sizeof(double);
+          8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8) + 64) * sizeof(double);
 }
 
 // number of packed teams (0: use the four-team / two-team kernels)
