@@ -412,6 +412,30 @@ __global__ void psi0_coef_beta_kernel(int64_t N, int D, const double* beta, doub
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = -0.5 * (double)D * (double)N * beta[0];
 }
 
+// All per-step tables of a layer in one launch: row offsets, prefix sums of the own / upper signal lengths, and the two
+// psi0 scalars (psi0 = N variance; its coefficient in the bound -D N / (2 noise)).
+__global__ void svi_tables_kernel(int n_seq, int X_win, const int64_t* __restrict__ own_len, const int64_t* __restrict__ up_len,
+                                  int64_t* row_off, int64_t* own_pre, int64_t* up_pre, int64_t N, int D,
+                                  const double* variance, const double* noise, double* psi0sum, double* psi0coef) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int64_t acc = 0;
+    for (int s = 0; s < n_seq; ++s) { row_off[s] = acc; acc += own_len[s] - X_win; }
+    row_off[n_seq] = acc;
+  } else if (t == 1) {
+    int64_t acc = 0;
+    for (int s = 0; s < n_seq; ++s) { own_pre[s] = acc; acc += own_len[s]; }
+    own_pre[n_seq] = acc;
+  } else if (t == 2 && up_len) {
+    int64_t acc = 0;
+    for (int s = 0; s < n_seq; ++s) { up_pre[s] = acc; acc += up_len[s]; }
+    up_pre[n_seq] = acc;
+  } else if (t == 3) {
+    psi0sum[0] = (double)N * variance[0];
+    psi0coef[0] = -0.5 * (double)D * (double)N / noise[0];
+  }
+}
+
 __global__ void prefix_kernel(int n_seq, const int64_t* __restrict__ len, int64_t* pre) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int64_t acc = 0;
@@ -921,9 +945,9 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
   if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   // tables + rows
-  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
-  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
-  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
+                     in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
+                     L.psi0sum, L.psi0coef);
   const WindowSpec w = svi_window_spec(in, L);
   launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
   launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
@@ -996,10 +1020,11 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
                     in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
     const int rb = psi1_svi_rows_blocks(N);
-    launch_reduce(s, L.nblk1, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
-    launch_reduce(s, rb, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
-    launch_reduce(s, rb, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
-    launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+    const ReduceSeg segs[4] = {{L.psi1Y_part, L.psi1Y, L.nblk1, (int64_t)D * M, (int64_t)D * M},
+                               {L.dlam1_part, L.dlam1, rb, QP, QP},
+                               {L.lsum1_part, L.lsum1, rb, 1, 1},
+                               {L.dz1_part, L.dz1, L.nblk1, (int64_t)M * QP, (int64_t)M * QP}};
+    launch_reduce_batch(s, 4, segs);
   } else {
     launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
     if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));
@@ -1029,14 +1054,13 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     prof_end(h);
     if (st) return st;
     const int tri = M * (M + 1) / 2;
-    launch_reduce(s, pl.n_p2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
+    const ReduceSeg segs[4] = {{L.p2_part, L.p2_tri, pl.n_p2, tri, tri},
+                               {L.dz2_part, L.dz2, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM},
+                               {L.dlam2_part, L.dlam2, pl.n_dl, QP, QP},
+                               {L.wsum2_part, L.wsum2, pl.n_dl, 1, 1}};
+    launch_reduce_batch(s, 4, segs);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
-    launch_reduce(s, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, pl.n_dl, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, pl.n_dl, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
   }
-  hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
-  hipLaunchKernelGGL(psi0_coef_kernel, dim3(1), dim3(64), 0, s, N, D, in->noise, L.psi0coef);
 
   // latent gradients (main stream; they need only the row gradients and dL/dY)
   int npart = 0;

@@ -1647,6 +1647,43 @@ void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const d
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(256), 0, s, nblk, len, stride, part, out, scale, accumulate);
 }
 
+// Several reductions in one launch (same arithmetic and order as reduce_kernel): the partial arrays of one pass are
+// reduced together, which removes 3-4 launches of latency-bound 30 us kernels per pass from the step's critical path.
+__global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceBatch rb) {
+  __shared__ double sm[8][33];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < REDUCE_BATCH_MAX; ++j)
+    if (j < rb.nseg && (int)blockIdx.x >= rb.blk_off[j]) k = j;
+  const ReduceSeg sg = rb.seg[k];
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t i = (int64_t)(blockIdx.x - rb.blk_off[k]) * 32 + e;
+  double s = 0.0;
+  if (i < sg.len) {
+    for (int b = g; b < sg.nblk; b += 8) s += sg.part[(size_t)b * sg.stride + i];
+  }
+  sm[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < sg.len) {
+    double tot = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) tot += sm[kk][e];
+    sg.out[i] = tot;
+  }
+}
+
+void launch_reduce_batch(hipStream_t s, int nseg, const ReduceSeg* segs) {
+  ReduceBatch rb{};
+  rb.nseg = nseg;
+  int off = 0;
+  for (int j = 0; j < nseg; ++j) {
+    rb.seg[j] = segs[j];
+    rb.blk_off[j] = off;
+    off += (int)((segs[j].len + 31) / 32);
+  }
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3(off), dim3(256), 0, s, rb);
+}
+
 __global__ void __launch_bounds__(256) unpack_tri_kernel(int M, const double* __restrict__ tri, double* __restrict__ full) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * M) return;
