@@ -10,6 +10,7 @@ struct SviChain {
   // workspace (device, carved by svi_chain_carve)
   double *Linv, *S, *Ls, *LsInv, *E, *EEt, *B, *A, *T1, *T2, *T3, *mA, *Kinv, *Gv;
   double *dLdpsi2, *dKmm;                               // results consumed by the psi backward / K backward
+  double *Sinv, *dKLdK;                                 // KL gradient terms, produced by stage 1b for stage 2
   double *gmu, *Kinv_mu, *Cpsi1, *Ybt, *gqm;
   double *scal, *bound, *dthetaL;
   // optional outputs (device, caller owned; may be null)
@@ -19,7 +20,8 @@ struct SviChain {
 
 size_t svi_chain_ws_doubles(int M, int D);
 void svi_chain_carve(SviChain& c, WsAlloc& ws);
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t s);
+// two kernels: (a) K_uu factor + Cpsi1 (ev_after_a, if given, is recorded after it), (b) dL_dpsi2 and the KL terms
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t s, hipEvent_t ev_after_a = nullptr);
 rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c, hipStream_t s);
 
 // ---- collapsed (Titsias) bound, autoreg/inference/vardtc.py:88-208 ------------------------------------------------

@@ -141,19 +141,43 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
   for (int k0 = 0; k0 < k; k0 += GP_K) {
     const int kb = (k - k0 < GP_K) ? k - k0 : GP_K;
     __syncthreads();
-    for (int e = threadIdx.x; e < GP_K * 128; e += blockDim.x) {
+    // branch-free staging: all loads of the two panels are issued before the first is consumed (a guarded load per
+    // element compiled to a load -> wait -> store chain, one global-memory latency per element)
+    constexpr int PE = GP_K * 128 / CH_THREADS;          // panel elements per thread
+    double va[PE], vb[PE];
+#pragma unroll
+    for (int u = 0; u < PE; ++u) {
+      const int e = threadIdx.x + u * CH_THREADS;
       int kk, i;
       if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }      // coalesced along the stored rows
-      double v = 0.0;
-      if (kk < kb && i < m) v = TA ? A[(size_t)(k0 + kk) * lda + i] : A[(size_t)i * lda + k0 + kk];
-      Ap[kk * GP_LD + i] = v;
+      const bool ok = kk < kb && i < m;
+      const int kc = ok ? k0 + kk : 0, ic = ok ? i : 0;
+      const double v = TA ? A[(size_t)kc * lda + ic] : A[(size_t)ic * lda + kc];
+      va[u] = ok ? v : 0.0;
     }
-    for (int e = threadIdx.x; e < GP_K * 128; e += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < PE; ++u) {
+      const int e = threadIdx.x + u * CH_THREADS;
       int kk, jx;
       if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
-      double v = 0.0;
-      if (kk < kb && jx < n) v = TB ? B[(size_t)jx * ldb + k0 + kk] : B[(size_t)(k0 + kk) * ldb + jx];
-      Bp[kk * GP_LD + jx] = v;
+      const bool ok = kk < kb && jx < n;
+      const int kc = ok ? k0 + kk : 0, jc = ok ? jx : 0;
+      const double v = TB ? B[(size_t)jc * ldb + kc] : B[(size_t)kc * ldb + jc];
+      vb[u] = ok ? v : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PE; ++u) {
+      const int e = threadIdx.x + u * CH_THREADS;
+      int kk, i;
+      if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }
+      Ap[kk * GP_LD + i] = va[u];
+    }
+#pragma unroll
+    for (int u = 0; u < PE; ++u) {
+      const int e = threadIdx.x + u * CH_THREADS;
+      int kk, jx;
+      if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
+      Bp[kk * GP_LD + jx] = vb[u];
     }
     __syncthreads();
     if (has) {
@@ -186,8 +210,8 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
   __syncthreads();
 }
 
-// ---- stage 1: everything that does not depend on the data statistics ---------------------------------------------
-__global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
+// ---- stage 1a: K_uu factor and dL/dpsi1 coefficients (what the psi1 passes wait for) -------------------------------
+__global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_a_kernel(SviChain c) {
   extern __shared__ double lds[];
   __shared__ double scratch[16];
   const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
@@ -198,6 +222,21 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
   double ldm = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
   lds_trtri(lds, M, ld);
   copy_out(c.Linv, lds, ld, M);
+  // gmu = Linv mu ; Kinv_mu = Linv^T gmu                          (svi_vardtc.py:97,153)
+  wg_gemm<false, false>(M, D, M, 1.0, c.Linv, M, c.qU_m, D, 0.0, c.gmu, D, lds);
+  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.gmu, D, 0.0, c.Kinv_mu, D, lds);
+  // dL_dpsi1 = beta Ymean Kinv_mu^T -> coefficient matrix          (:164-167)
+  for (int i = t; i < M * D; i += blockDim.x) c.Cpsi1[i] = beta * c.Kinv_mu[i];
+  if (t == 0) c.scal[0] = ldm;      // sum log diag Lm
+}
+
+// ---- stage 1b: the rest of the data-independent algebra (dL/dpsi2 for the psi2 pass; KL terms for stage 2) ----------
+__global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c) {
+  extern __shared__ double lds[];
+  __shared__ double scratch[16];
+  const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
+  const double Dd = (double)D;
+  const double beta = 1.0 / c.noise[0];
   // S = W W^T + a I ; Ls ; LsInv                                  (layers.py:71, svi_vardtc.py:95)
   wg_gemm<false, true>(M, M, M, 1.0, c.qU_W, M, c.qU_W, M, 0.0, c.S, M, lds);
   if (t < M) c.S[t * M + t] += c.qU_a[0];
@@ -208,26 +247,29 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_kernel(SviChain c) {
   copy_out(c.Ls, lds, ld, M);
   lds_trtri(lds, M, ld);
   copy_out(c.LsInv, lds, ld, M);
-  // E = Linv Ls ; gmu = Linv mu ; Kinv_mu = Linv^T gmu            (svi_vardtc.py:96-97,153)
+  // E = Linv Ls                                                   (svi_vardtc.py:96)
   wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.Ls, M, 0.0, c.E, M, lds);
-  wg_gemm<false, false>(M, D, M, 1.0, c.Linv, M, c.qU_m, D, 0.0, c.gmu, D, lds);
-  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.gmu, D, 0.0, c.Kinv_mu, D, lds);
   // B = D E E^T + gmu gmu^T                                       (:111)
   wg_gemm<false, true>(M, M, M, 1.0, c.E, M, c.E, M, 0.0, c.EEt, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.B[i] = (double)D * c.EEt[i];
+  for (int i = t; i < M * M; i += blockDim.x) c.B[i] = Dd * c.EEt[i];
   __syncthreads();
   wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.gmu, D, 1.0, c.B, M, lds);
   // dL_dpsi2 = beta/2 Linv^T (D I - B) Linv                       (:169), symmetric by construction
-  for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? (double)D : 0.0) - c.B[i];
+  for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? Dd : 0.0) - c.B[i];
   __syncthreads();
   wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
   wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
-  // dL_dpsi1 = beta Ymean Kinv_mu^T -> coefficient matrix          (:164-167)
-  for (int i = t; i < M * D; i += blockDim.x) c.Cpsi1[i] = beta * c.Kinv_mu[i];
-  if (t == 0) {
-    c.scal[0] = ldm;      // sum log diag Lm
-    c.scal[1] = lds_;     // sum log diag Ls
-  }
+  if (t == 0) c.scal[1] = lds_;     // sum log diag Ls
+  // KL gradient terms (:211-213), independent of the statistics: Kinv = Linv^T Linv, Sinv = LsInv^T LsInv,
+  // V = mu mu^T + D S, dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv.  (T1..T3 are free again: stage 2 starts after this kernel.)
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
+  wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.Sinv, M, lds);
+  for (int i = t; i < M * M; i += blockDim.x) c.T2[i] = Dd * c.S[i];
+  __syncthreads();
+  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T2, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Kinv, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.Kinv, M, c.T1, M, 0.0, c.T3, M, lds);
+  for (int i = t; i < M * M; i += blockDim.x) c.dKLdK[i] = 0.5 * Dd * c.Kinv[i] - 0.5 * c.T3[i];
 }
 
 // ---- stage 2: after the statistics are known --------------------------------------------------------------------
@@ -275,20 +317,13 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   wg_gemm<true, false>(M, M, M, -1.0, c.Linv, M, c.T1, M, 0.0, c.mA, M, lds);
   wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 0.0, c.gqm, D, lds);
   wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.Ybt, D, 1.0, c.gqm, D, lds);
-  // KL gradients (:211-213): Kinv = Linv^T Linv, Sinv = LsInv^T LsInv
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
-  wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.T1, M, lds);   // Sinv
+  // KL gradients (:211-213) with Kinv, Sinv and dKL_dK from stage 1b
   // Gv = dL_dqU_var - ratio dKL_dvar = D/2 mA - ratio D/2 (Kinv - Sinv)
-  for (int i = t; i < M * M; i += blockDim.x) c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.T1[i]);
+  for (int i = t; i < M * M; i += blockDim.x) {
+    c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);
+    c.dKmm[i] -= ratio * c.dKLdK[i];
+  }
   for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] -= ratio * c.Kinv_mu[i];
-  __syncthreads();
-  // V = mu mu^T + D S ; dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv
-  for (int i = t; i < M * M; i += blockDim.x) c.T2[i] = Dd * c.S[i];
-  __syncthreads();
-  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T2, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Kinv, M, 0.0, c.T1, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, c.Kinv, M, c.T1, M, 0.0, c.T3, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.dKmm[i] -= ratio * (0.5 * Dd * c.Kinv[i] - 0.5 * c.T3[i]);
   __syncthreads();
   // q(U) parameter gradients (layers.py:173-176)
   if (c.gqU_m) for (int i = t; i < M * D; i += blockDim.x) c.gqU_m[i] = c.gqm[i];
@@ -313,7 +348,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
 }
 
 size_t svi_chain_ws_doubles(int M, int D) {
-  return (size_t)16 * M * M + 6 * (size_t)M * D + 64;
+  return (size_t)18 * M * M + 6 * (size_t)M * D + 64;
 }
 
 void svi_chain_carve(SviChain& c, WsAlloc& ws) {
@@ -322,18 +357,25 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
   c.E = ws.take<double>(mm); c.EEt = ws.take<double>(mm); c.B = ws.take<double>(mm); c.A = ws.take<double>(mm);
   c.T1 = ws.take<double>(mm); c.T2 = ws.take<double>(mm); c.T3 = ws.take<double>(mm); c.mA = ws.take<double>(mm);
   c.Kinv = ws.take<double>(mm); c.Gv = ws.take<double>(mm); c.dLdpsi2 = ws.take<double>(mm); c.dKmm = ws.take<double>(mm);
+  c.Sinv = ws.take<double>(mm); c.dKLdK = ws.take<double>(mm);
   c.gmu = ws.take<double>(md); c.Kinv_mu = ws.take<double>(md); c.Cpsi1 = ws.take<double>(md); c.Ybt = ws.take<double>(md);
   c.gqm = ws.take<double>(md);
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1);
 }
 
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream) {
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream, hipEvent_t ev_after_a) {
   if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
   size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
-  hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)svi_chain_pre_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain LDS attr: ") + hipGetErrorString(e));
-  hipLaunchKernelGGL(svi_chain_pre_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
+  hipLaunchKernelGGL(svi_chain_pre_a_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
+  if (ev_after_a) {
+    e = hipEventRecord(ev_after_a, stream);
+    if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(svi_chain_pre_b_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
   return RGP_OK;
 }
 

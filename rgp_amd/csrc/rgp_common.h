@@ -73,9 +73,12 @@ struct rgp_ctx {
   int prepared_slot[NSLOT] = {0, 0, 0, 0};
   bool overlap = true;
   bool deterministic = false;       // rgp_set_deterministic: fixed-order psi2 kernels only
-  hipStream_t side_pre = nullptr, side_post = nullptr;
+  hipStream_t side_pre = nullptr, side_post = nullptr, side_rows = nullptr;
   hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
   hipEvent_t ev_pre[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_pre_a[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // K_uu factor + Cpsi1 ready (psi1 passes)
+  hipEvent_t ev_rows[NSLOT] = {nullptr, nullptr, nullptr, nullptr};    // window tables + row terms ready (side_rows stream)
+  hipEvent_t ev_main = nullptr;                                          // main-stream position at prepare time
   hipEvent_t ev_done[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
   bool done_recorded[NSLOT] = {false, false, false, false};
   int* status = nullptr;        // device: [0] = error code, [1] = pivot

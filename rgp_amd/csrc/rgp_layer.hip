@@ -30,6 +30,7 @@ rgp_status rgp_ensure_ws_slot(rgp_handle h, int slot, size_t bytes) {
   (void)hipStreamSynchronize(h->stream);
   if (h->side_pre) (void)hipStreamSynchronize(h->side_pre);
   if (h->side_post) (void)hipStreamSynchronize(h->side_post);
+  if (h->side_rows) (void)hipStreamSynchronize(h->side_rows);
   if (h->ws_slot[slot]) (void)hipFree(h->ws_slot[slot]);
   h->ws_slot[slot] = nullptr; h->ws_slot_bytes[slot] = 0;
   bytes = bytes + bytes / 8 + (1u << 20);
@@ -66,11 +67,15 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
   h->overlap = getenv("RGP_NO_OVERLAP") == nullptr;
   if (hipStreamCreateWithFlags(&h->side_pre, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+      hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->side_rows, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming);
   for (int k = 0; k < rgp_ctx::NSLOT; ++k) {
     hipEventCreateWithFlags(&h->ev_pre[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_pre_a[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_rows[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
   }
   *out = h;
@@ -83,6 +88,7 @@ extern "C" void rgp_destroy(rgp_handle h) {
   hipStreamSynchronize(h->stream);
   if (h->side_pre) { hipStreamSynchronize(h->side_pre); hipStreamDestroy(h->side_pre); }
   if (h->side_post) { hipStreamSynchronize(h->side_post); hipStreamDestroy(h->side_post); }
+  if (h->side_rows) { hipStreamSynchronize(h->side_rows); hipStreamDestroy(h->side_rows); }
   if (h->ws) hipFree(h->ws);
   for (int k = 0; k < rgp_ctx::NSLOT; ++k) if (h->ws_slot[k]) hipFree(h->ws_slot[k]);
   if (h->status) hipFree(h->status);
@@ -931,8 +937,14 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   const int slot = h->slot_next;
   h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
   if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
-  hipStream_t s = h->stream;
+  hipStream_t s = h->overlap ? h->side_rows : h->stream;      // everything below is off the main stream
   hipStream_t s_pre = h->overlap ? h->side_pre : s;
+  if (h->overlap) {
+    // parameters and signals are written by main-stream work (the previous step's update), and the slot's previous user
+    // on the main stream must be finished too
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_main, h->stream));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_main, 0));
+  }
   // the side-stream work that last used this slot must be finished before it is overwritten
   if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
   carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
@@ -942,7 +954,7 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
   }
-  if ((st = launch_svi_chain_pre(h, c, s_pre))) return st;
+  if ((st = launch_svi_chain_pre(h, c, s_pre, h->overlap ? h->ev_pre_a[slot] : nullptr))) return st;
   if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   // tables + rows
   hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
@@ -951,6 +963,7 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   const WindowSpec w = svi_window_spec(in, L);
   launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
   launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_rows[slot], s));
   *slot_out = slot;
   return RGP_OK;
 }
@@ -1007,8 +1020,9 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
   const int QP = L.zt.QP;
 
-  // the window tables and row terms were produced by svi_prepare_slot (main stream)
+  // the window tables and row terms were produced by svi_prepare_slot (side_rows stream)
   WindowSpec w = svi_window_spec(in, L);
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_rows[slot], 0));
 
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
@@ -1016,7 +1030,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // psi1 side
   if (psi1_svi_supported(D)) {
-    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));    // Cpsi1 / dL_dpsi2 come from the chain
+    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_a[slot], 0));  // Cpsi1 comes from the chain's first kernel
     launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
                     in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
     const int rb = psi1_svi_rows_blocks(N);
@@ -1043,6 +1057,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   }
 
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));      // dL_dpsi2 comes from the chain's second kernel
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
   {
     Psi2Out o{};
