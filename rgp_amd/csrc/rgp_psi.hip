@@ -16,6 +16,34 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
+// n = rint(x * 64/ln2) = 64 k + j, r = x - n ln2/64 (|r| <= ln2/128) and q the degree-5 Taylor polynomial of expm1 (next term
+// r^6/720 < 4e-17).  T[j] = 2^(j/64) is a 64-entry LDS table.  15 VALU instructions and one LDS read instead of the ~36
+// (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp (the
+// rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register sources:
+// the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
+#define PSI2_EXP_TAB 64
+static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
+  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
+  const double t = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);          // 64/ln2; integer n in the low mantissa bits
+  const int n = __double2loint(t);
+  const double nf = t - 0x1.8p52;
+  double r = fma(nf, -0x1.62e42fefa0000p-7, x);                     // ln2/64 split: high part has 33 significant bits
+  r = fma(nf, -0x1.cf79abc9e3b3ap-46, r);
+  const double tj = T[n & (PSI2_EXP_TAB - 1)];
+  double q = fma_rrr(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);      // 1/120, 1/24
+  q = fma_rrr(q, r, 0x1.5555555555555p-3);                                 // 1/6
+  q = fma_rrr(q, r, 0.5);
+  q = fma_rrr(q, r, 1.0);
+  q = q * r;
+  return ldexp(fma(tj, q, tj), n >> 6);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Z-derived terms
 // ------------------------------------------------------------------------------------------------------------------
@@ -419,7 +447,9 @@ void launch_psi1_dz(hipStream_t s, int64_t N, int M, const ZTerms& zt, const Row
 //   pass Z (thread = inducing row m):  dZ[m,q] = sum_n Lp[n,m] (e mu - e z)[n,q]
 // Each layout makes one of the two reductions thread-local.  Row operands that are uniform over a workgroup (e, e*mu, Ym)
 // are staged in LDS and read as broadcasts: 2*QP doubles per row do not fit the SGPR file (the scalar-operand version of
-// the forward spilled 105 SGPRs per row through v_writelane and ran 5 load-wait phases per row).
+// the forward spilled 105 SGPRs per row through v_writelane and ran 5 load-wait phases per row; a spill-free variant with
+// two half-row scalar loads per row measured 475 us against 165 us for the LDS version: one row per wave-iteration leaves
+// the scalar-load latency exposed).
 // ------------------------------------------------------------------------------------------------------------------
 #define P1_TILE 32                 // rows staged per tile, 16 per team of 128 threads
 
@@ -1197,34 +1227,6 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 //   * the per-row reductions over m split each wave's transposed sum at the team boundary.
 // ------------------------------------------------------------------------------------------------------------------
 #define PSI2_MAX_NT 8
-
-// exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
-// n = rint(x * 64/ln2) = 64 k + j, r = x - n ln2/64 (|r| <= ln2/128) and q the degree-5 Taylor polynomial of expm1 (next term
-// r^6/720 < 4e-17).  T[j] = 2^(j/64) is a 64-entry LDS table.  15 VALU instructions and one LDS read instead of the ~36
-// (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp (the
-// rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register sources:
-// the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
-#define PSI2_EXP_TAB 64
-static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
-  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
-  const double t = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);          // 64/ln2; integer n in the low mantissa bits
-  const int n = __double2loint(t);
-  const double nf = t - 0x1.8p52;
-  double r = fma(nf, -0x1.62e42fefa0000p-7, x);                     // ln2/64 split: high part has 33 significant bits
-  r = fma(nf, -0x1.cf79abc9e3b3ap-46, r);
-  const double tj = T[n & (PSI2_EXP_TAB - 1)];
-  double q = fma_rrr(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);      // 1/120, 1/24
-  q = fma_rrr(q, r, 0x1.5555555555555p-3);                                 // 1/6
-  q = fma_rrr(q, r, 0.5);
-  q = fma_rrr(q, r, 1.0);
-  q = q * r;
-  return ldexp(fma(tj, q, tj), n >> 6);
-}
 
 template <int QP>
 static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
