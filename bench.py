@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X public fp64 peak (vector = matrix); the local guide lists none. Measured by
-                             # tools/f64_peak.hip on this pool (profiles/r1_f64_peak.txt): v_fma_f64 63.5 TF at 2 waves/SIMD,
+                             # tools/f64_peak.hip / f64_lat.hip on this pool (profiles/r1_f64_peak.txt, r1_f64_lat.txt): v_fma_f64 63.5 TF at 2 waves/SIMD,
                              # 68.2 TF at 8; v_mfma_f64_16x16x4 45.6 / 49.4 TF.
 
 
@@ -32,7 +32,7 @@ def measured_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs; FETCH_SIZE doubled as the gfx950 guide prescribes for wide coalesced reads).  None if absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r1_psi2_rows4_traffic_raw.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r1_psi2_rowsN_traffic_raw.json')))
         return (2.0 * d['FETCH_SIZE']['avg_per_launch_kb'] + d['WRITE_SIZE']['avg_per_launch_kb']) * 1024.0
     except Exception:
         return None
@@ -141,8 +141,8 @@ def main():
             'elbo_last_step': elbo,
             'roofline': {'bound': 'mfma', 'bound_note': 'fp64 compute (VALU); the fp64 matrix pipe is slower than the vector pipe on MI355X, see DESIGN.md', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': measured_traffic_bytes(),
-                         'traffic_note': 'bytes per Q=40 launch from a separate rocprofv3 --pmc pass (profiles/r1_psi2_rows4_traffic_raw.json); algorithmic ~0.25e9',
-                         'kernel': 'psi2_rows4_kernel (fused psi2 forward+backward, fp64 VALU, 3 launches per step: Q=40,40,20)',
+                         'traffic_note': 'bytes per Q=40 launch from a separate rocprofv3 --pmc pass (profiles/r1_psi2_rowsN_traffic_raw.json); algorithmic ~0.25e9',
+                         'kernel': 'psi2_rowsN_kernel (fused psi2 forward+backward, packed teams, fp64 VALU, 3 launches per step: Q=40,40,20)',
                          'avg_launch_ms': psi2_ms / max(psi2_n, 1), 'launches': psi2_n,
                          'algorithmic_flop_per_launch': flops / max(psi2_n, 1),
                          'note': 'flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
