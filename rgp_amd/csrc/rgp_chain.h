@@ -20,8 +20,10 @@ struct SviChain {
 
 size_t svi_chain_ws_doubles(int M, int D);
 void svi_chain_carve(SviChain& c, WsAlloc& ws);
-// two kernels: (a) K_uu factor + Cpsi1 (ev_after_a, if given, is recorded after it), (b) dL_dpsi2 and the KL terms
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t s, hipEvent_t ev_after_a = nullptr);
+// three kernels: (a) K_uu factor + Cpsi1, (b) dL_dpsi2, (c) KL gradient terms; the events, if given, are recorded after
+// (a) and (b)
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t s, hipEvent_t ev_after_a = nullptr,
+                                hipEvent_t ev_after_b = nullptr);
 rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c, hipStream_t s);
 
 // ---- collapsed (Titsias) bound, autoreg/inference/vardtc.py:88-208 ------------------------------------------------

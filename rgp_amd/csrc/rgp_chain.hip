@@ -230,14 +230,14 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_a_kernel(SviChain c)
   if (t == 0) c.scal[0] = ldm;      // sum log diag Lm
 }
 
-// ---- stage 1b: the rest of the data-independent algebra (dL/dpsi2 for the psi2 pass; KL terms for stage 2) ----------
+// ---- stage 1b: dL/dpsi2 (what the psi2 pass waits for) -------------------------------------------------------------
 __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c) {
   extern __shared__ double lds[];
   __shared__ double scratch[16];
   const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
   const double Dd = (double)D;
   const double beta = 1.0 / c.noise[0];
-  // S = W W^T + a I ; Ls ; LsInv                                  (layers.py:71, svi_vardtc.py:95)
+  // S = W W^T + a I ; Ls                                          (layers.py:71, svi_vardtc.py:95)
   wg_gemm<false, true>(M, M, M, 1.0, c.qU_W, M, c.qU_W, M, 0.0, c.S, M, lds);
   if (t < M) c.S[t * M + t] += c.qU_a[0];
   __syncthreads();
@@ -245,8 +245,6 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c)
   lds_chol(lds, M, ld, c.status);
   double lds_ = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
   copy_out(c.Ls, lds, ld, M);
-  lds_trtri(lds, M, ld);
-  copy_out(c.LsInv, lds, ld, M);
   // E = Linv Ls                                                   (svi_vardtc.py:96)
   wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.Ls, M, 0.0, c.E, M, lds);
   // B = D E E^T + gmu gmu^T                                       (:111)
@@ -260,8 +258,17 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c)
   wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
   wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
   if (t == 0) c.scal[1] = lds_;     // sum log diag Ls
-  // KL gradient terms (:211-213), independent of the statistics: Kinv = Linv^T Linv, Sinv = LsInv^T LsInv,
-  // V = mu mu^T + D S, dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv.  (T1..T3 are free again: stage 2 starts after this kernel.)
+}
+
+// ---- stage 1c: KL gradient terms (:211-213), independent of the statistics, needed only by stage 2 -----------------
+//   LsInv, Kinv = Linv^T Linv, Sinv = LsInv^T LsInv, V = mu mu^T + D S, dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv
+__global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_c_kernel(SviChain c) {
+  extern __shared__ double lds[];
+  const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
+  const double Dd = (double)D;
+  copy_in(lds, ld, c.Ls, M);
+  lds_trtri(lds, M, ld);
+  copy_out(c.LsInv, lds, ld, M);
   wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
   wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.Sinv, M, lds);
   for (int i = t; i < M * M; i += blockDim.x) c.T2[i] = Dd * c.S[i];
@@ -363,19 +370,21 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1);
 }
 
-rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream, hipEvent_t ev_after_a) {
+rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream, hipEvent_t ev_after_a, hipEvent_t ev_after_b) {
   if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
   size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)svi_chain_pre_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)svi_chain_pre_c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain LDS attr: ") + hipGetErrorString(e));
   hipLaunchKernelGGL(svi_chain_pre_a_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
-  if (ev_after_a) {
-    e = hipEventRecord(ev_after_a, stream);
-    if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
-  }
+  if (ev_after_a && (e = hipEventRecord(ev_after_a, stream)) != hipSuccess)
+    return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
   hipLaunchKernelGGL(svi_chain_pre_b_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
+  if (ev_after_b && (e = hipEventRecord(ev_after_b, stream)) != hipSuccess)
+    return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(svi_chain_pre_c_kernel, dim3(1), dim3(CH_THREADS), lds, stream, c);
   return RGP_OK;
 }
 

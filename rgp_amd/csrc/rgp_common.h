@@ -77,6 +77,7 @@ struct rgp_ctx {
   hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
   hipEvent_t ev_pre[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_pre_a[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // K_uu factor + Cpsi1 ready (psi1 passes)
+  hipEvent_t ev_pre_b[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // dL_dpsi2 ready (psi2 pass)
   hipEvent_t ev_rows[NSLOT] = {nullptr, nullptr, nullptr, nullptr};    // window tables + row terms ready (side_rows stream)
   hipEvent_t ev_main = nullptr;                                          // main-stream position at prepare time
   hipEvent_t ev_done[NSLOT] = {nullptr, nullptr, nullptr, nullptr};

@@ -76,6 +76,7 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
     hipEventCreateWithFlags(&h->ev_pre[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_pre_a[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_rows[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_pre_b[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
   }
   *out = h;
@@ -954,7 +955,7 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
   }
-  if ((st = launch_svi_chain_pre(h, c, s_pre, h->overlap ? h->ev_pre_a[slot] : nullptr))) return st;
+  if ((st = launch_svi_chain_pre(h, c, s_pre, h->overlap ? h->ev_pre_a[slot] : nullptr, h->overlap ? h->ev_pre_b[slot] : nullptr))) return st;
   if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   // tables + rows
   hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
@@ -1057,7 +1058,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   }
 
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));      // dL_dpsi2 comes from the chain's second kernel
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_b[slot], 0));    // dL_dpsi2 comes from the chain's second kernel
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
   {
     Psi2Out o{};
