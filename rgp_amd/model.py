@@ -69,14 +69,14 @@ class DeepAutoreg(object):
 
     wins[0] is the observed layer's own window (must be 0, as in the reference), wins[i>0] the hidden windows;
     ``self.layers`` is ordered top layer first like the reference's ``model.layers`` (model.py:94-109).
-    Not in this build ("next"): ``back_cstr=True`` (MLP / RNN recognition models)."""
+    Back-constraints are separate classes: ``DeepAutoreg_rnn`` (sequence encoder) and ``DeepAutoreg_mlp`` (MLP recursion)."""
 
     def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10, likelihood=None,
                  name='autoreg', kernels=None, U_pre_step=True, init='Y', inducing_init='rand', back_cstr=False,
                  MLP_dims=None, inference_method='svi', minibatch_inference=False, mb_inf_tot_data_size=None,
                  mb_inf_sample_idxes=None, device=None, seed=0, Zs=None, latent_full=False):
         if back_cstr:
-            raise NotImplementedError('back-constraints (autoreg/mlp.py, rnn_encoder.py) are outside this build (SURVEY 8f)')
+            raise NotImplementedError('use DeepAutoreg_mlp (MLP recursion) or DeepAutoreg_rnn (sequence encoder) for back-constraints')
         if not U_pre_step:
             raise NotImplementedError('U_pre_step=False')
         assert wins[0] == 0, 'the observed layer cannot be autoregressive (as in the reference)'
@@ -669,6 +669,100 @@ class DeepAutoreg_rnn(DeepAutoreg):
             for p in self.encoder.parameters():
                 p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
+            elbo = self.grad_array[self.elbo_slot]
+        if not update:
+            return elbo
+        ad['t_glob'] += 1
+        G = self.n_global
+        h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
+                    self.positive[:G], lr, ad['t_glob'])
+        for g in self._enc_opt.param_groups:
+            g['lr'] = lr
+        self._enc_opt.step()
+        return elbo
+
+
+class DeepAutoreg_mlp(DeepAutoreg):
+    """autoreg.DeepAutoreg(..., back_cstr=True) (model.py:30-187 with layers.py:398-441,623-756): the predicted latent means
+    of every hidden layer are the output of an MLP recursion over the layer's own past and the signal above; trainable are
+    the GP globals, the first X_win latent rows, the latent variances and the MLP weights.  The GP layers run through
+    librgp_hip.so exactly as in DeepAutoreg; the recursion and its back-propagation are PyTorch-ROCm fp64
+    (rgp_amd/mlp_encoder.py).  Sequences must have equal length (they are batched through the recursion)."""
+
+    def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10, kernels=None,
+                 MLP_dims=None, inference_method='svi', mb_inf_tot_data_size=None, device=None, seed=0, Zs=None, **kw):
+        from .mlp_encoder import MlpBackConstraint
+        Ys = [Y] if isinstance(Y, np.ndarray) else list(Y)
+        Us = None if U is None else ([U] if isinstance(U, np.ndarray) else list(U))
+        assert len(set(y.shape[0] for y in Ys)) == 1, 'the batched recursion needs equal-length sequences'
+        DeepAutoreg.__init__(self, wins, Ys, U=Us, U_win=U_win, nDims=nDims, X_variance=X_variance, num_inducing=num_inducing,
+                             kernels=kernels, init='Y', inference_method=inference_method,
+                             mb_inf_tot_data_size=mb_inf_tot_data_size, device=device, seed=seed, Zs=Zs, **kw)
+        torch.manual_seed(seed)
+        specs = []
+        for i in range(self.nLayers - 1, 0, -1):                                 # top hidden layer first
+            L = self.layer(i)
+            up_len = int(self.u_len[0]) if (i == self.nLayers - 1 and Us is not None) else \
+                (int(self.lat_len[i + 1][0]) if i < self.nLayers - 1 else 0)
+            specs.append(dict(index=i, X_win=L.X_win, X_dim=L.X_dim, U_win=L.U_win, U_dim=L.U_dim,
+                              N=int(self.lat_len[i][0]) - L.X_win, up_len=up_len))
+        self.encoder = MlpBackConstraint(specs, self.nSeq, X_variance=X_variance, MLP_dims=MLP_dims).to(self.device)
+        self.controls = None if Us is None else self.Ucat.view(self.nSeq, int(self.u_len[0]), self.Du)
+        self._enc_index = {}
+        for sp in specs:
+            i, H = sp['index'], self.nDims[sp['index']]
+            T = int(self.lat_len[i][0])
+            base = torch.as_tensor(self.lat_off[i], device=self.device).view(-1, 1, 1)
+            t = torch.arange(T, device=self.device).view(1, -1, 1) * H
+            hh = torch.arange(H, device=self.device).view(1, 1, -1)
+            self._enc_index[i] = base + t + hh                                    # (n_seq, T, H)
+        self._enc_out = None
+        self._enc_opt = None
+
+    def encode(self, seqs=None):
+        """Run the recursions for the sequences ``seqs`` and write q(X) of every hidden layer into the latent buffers."""
+        idx = slice(None) if seqs is None else (seqs if isinstance(seqs, slice) else torch.as_tensor(list(seqs), device=self.device))
+        means, variances = self.encoder(self.controls, idx)
+        with torch.no_grad():
+            for sp, m, v in zip(self.encoder.specs, means, variances):
+                flat = self._enc_index[sp['index']][idx].reshape(-1)
+                self.means[flat] = m.reshape(-1)
+                self.vars[flat] = v.reshape(-1)
+        self._enc_out = (means, variances, idx)
+        return means, variances
+
+    def evaluate(self, seqs=None, qU_ratio=None, **kw):
+        """ELBO and gradients: GP globals in grad_array, recursion parameters in ``.grad`` (layers.py:668-756)."""
+        self.encode(seqs)
+        means, variances, idx = self._enc_out
+        elbo = DeepAutoreg.evaluate(self, seqs, qU_ratio=qU_ratio, **kw)
+        self.encoder.zero_grad()
+        outs, grads = [], []
+        for sp, m, v in zip(self.encoder.specs, means, variances):
+            flat = self._enc_index[sp['index']][idx].reshape(-1)
+            outs += [m, v]
+            grads += [self.gmeans[flat].view(m.shape), self.gvars[flat].view(v.shape)]
+        torch.autograd.backward(outs, grads)
+        self._enc_out = None
+        return elbo
+
+    def encoder_grad_vector(self):
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.encoder.parameters()])
+
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True):
+        """One SVI step: ELBO + gradients, optional all-reduce of the replicated parameters' gradients (GP globals and MLP
+        weights; the per-sequence latent parameters stay local), Adam on the GP globals (device kernel) and torch Adam on
+        the recursion parameters."""
+        if self._adam is None:
+            self._init_adam()
+        if self._enc_opt is None:
+            self._enc_opt = torch.optim.Adam(self.encoder.parameters(), lr=lr, maximize=True)
+        ad, h = self._adam, self.handle
+        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        if allreduce is not None:
+            allreduce(self.grad_array[:self.n_global + 1])
+            for p in self.encoder.nets.parameters():
+                allreduce(p.grad)
             elbo = self.grad_array[self.elbo_slot]
         if not update:
             return elbo
