@@ -120,6 +120,23 @@ rgp_status rgp_set_deterministic(rgp_handle h, int on);
  *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);
 
+/* ---- pipelining consecutive SVI steps -------------------------------------------------------------------------------
+ * The M x M chain of a layer needs only that layer's global parameters.  Once they have been updated, the chain of the
+ * NEXT step can start while the running step is still busy with the psi passes of later layers:
+ *   rgp_layer_step(L_k) ; [all-reduce of L_k's gradients on the stream rgp_get_stream(h, 1)] ;
+ *   rgp_adam_step_post(L_k's global parameters)            -- ordered after L_k's gradients on the library's side stream
+ *   rgp_layer_prepare(in_k with reserved = RGP_PREPARE_CHAIN_ONLY)
+ * and, at the start of the next step, rgp_layer_prepare(in_k with reserved = RGP_PREPARE_ROWS_ONLY) for every layer in the
+ * same order (window tables / row terms of the new minibatch; not larger than the one given to the chain-only call).
+ * rgp_discard_prepared drops prepared layers that will not be stepped (parameters changed by other means). */
+#define RGP_PREPARE_CHAIN_ONLY 1
+#define RGP_PREPARE_ROWS_ONLY 2
+rgp_status rgp_adam_step_post(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,
+                              const uint8_t* positive, double lr, double beta1, double beta2, double eps, int64_t step);
+rgp_status rgp_discard_prepared(rgp_handle h);
+/* which = 0: the handle's main stream; 1: the side stream that carries each layer's gradients (hipStream_t as void*). */
+rgp_status rgp_get_stream(rgp_handle h, int which, void** stream);
+
 /* ---- collapsed bound in two phases, for data-parallel use.  The reference's dead MPI stub all-reduces the sufficient
  *      statistics [psi0, psi2, YRY, psi1Y] (svi_vardtc.py:65-67); for the collapsed bound dL/dpsi2 depends on the GLOBAL
  *      psi2 (vardtc.py:141-142), so the exchange sits between the forward statistics and the M x M algebra.

@@ -57,7 +57,12 @@ SYMBOLS = {
     'rgp_freerun': (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [c_dp] * 9 + [C.c_double, C.c_int64, C.c_int64, c_dp, c_dp]),
     'rgp_adam_step': (C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_void_p, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int64]),
+    'rgp_adam_step_post': (C.c_int, [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_void_p, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, C.c_int64]),
+    'rgp_discard_prepared': (C.c_int, [C.c_void_p]),
+    'rgp_get_stream': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
 }
+PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY = 1, 2          # rgp_layer_in.reserved for rgp_layer_prepare
 
 _lib = None
 

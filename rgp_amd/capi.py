@@ -124,8 +124,22 @@ class Handle(object):
     def vardtc_finish(self, lin, lout, stats, N_global, weight):
         self._check(self.lib.rgp_vardtc_finish(self.h, C.byref(lin), C.byref(lout), _p(stats), int(N_global), float(weight)))
 
-    def layer_prepare(self, lin):
-        self._check(self.lib.rgp_layer_prepare(self.h, C.byref(lin)))
+    def layer_prepare(self, lin, flags=0):
+        """flags: 0 = chain + rows, PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY (include/rgp_hip.h, pipelining section)."""
+        old = lin.reserved
+        lin.reserved = int(flags)
+        try:
+            self._check(self.lib.rgp_layer_prepare(self.h, C.byref(lin)))
+        finally:
+            lin.reserved = old
+
+    def discard_prepared(self):
+        self._check(self.lib.rgp_discard_prepared(self.h))
+
+    def get_stream(self, which=0):
+        out = C.c_void_p(0)
+        self._check(self.lib.rgp_get_stream(self.h, int(which), C.byref(out)))
+        return out.value
 
     def layer_step(self, lin, lout):
         self._check(self.lib.rgp_layer_step(self.h, C.byref(lin), C.byref(lout)))
@@ -139,9 +153,11 @@ class Handle(object):
                                          float(u_var_const), int(u_rows), int(u_skip), _p(Xm), _p(Xv)))
         return Xm, Xv
 
-    def adam_step(self, x, p, g, m, v, positive, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    def adam_step(self, x, p, g, m, v, positive, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, post=False):
+        """post=True: on the library's side stream, ordered after the gradients of the last layer step (rgp_adam_step_post)."""
         n = x.numel()
-        self._check(self.lib.rgp_adam_step(self.h, n, _p(x), _p(p), _p(g), _p(m), _p(v),
+        fn = self.lib.rgp_adam_step_post if post else self.lib.rgp_adam_step
+        self._check(fn(self.h, n, _p(x), _p(p), _p(g), _p(m), _p(v),
                                            C.c_void_p(positive.data_ptr()) if positive is not None else None,
                                            float(lr), float(beta1), float(beta2), float(eps), int(step)))
 

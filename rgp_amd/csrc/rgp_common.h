@@ -65,23 +65,29 @@ struct rgp_ctx {
   // layer (side streams) can overlap the psi passes of the next layer (main stream).
   char* ws = nullptr;
   size_t ws_bytes = 0;
-  static const int NSLOT = 4;
-  char* ws_slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-  size_t ws_slot_bytes[NSLOT] = {0, 0, 0, 0};
+  static const int NSLOT = 8;        // ring of layer workspaces: the layers of one step plus the next step's early chains
+  char* ws_slot[NSLOT] = {};
+  size_t ws_slot_bytes[NSLOT] = {};
   int slot_next = 0;                 // next slot to hand out
   int prepared_head = 0, prepared_count = 0;   // FIFO of slots prepared by rgp_layer_prepare
-  int prepared_slot[NSLOT] = {0, 0, 0, 0};
+  int prepared_slot[NSLOT] = {};
+  bool prepared_rows[NSLOT] = {};     // FIFO entry also has its window tables / row terms (false: chain-only prepare)
   bool overlap = true;
   bool deterministic = false;       // rgp_set_deterministic: fixed-order psi2 kernels only
   hipStream_t side_pre = nullptr, side_post = nullptr, side_rows = nullptr;
   hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
-  hipEvent_t ev_pre[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_pre_a[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // K_uu factor + Cpsi1 ready (psi1 passes)
-  hipEvent_t ev_pre_b[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // dL_dpsi2 ready (psi2 pass)
-  hipEvent_t ev_rows[NSLOT] = {nullptr, nullptr, nullptr, nullptr};    // window tables + row terms ready (side_rows stream)
+  hipEvent_t ev_pre[NSLOT] = {};
+  hipEvent_t ev_pre_a[NSLOT] = {};   // K_uu factor + Cpsi1 ready (psi1 passes)
+  hipEvent_t ev_pre_b[NSLOT] = {};   // dL_dpsi2 ready (psi2 pass)
+  hipEvent_t ev_rows[NSLOT] = {};    // window tables + row terms ready (side_rows stream)
   hipEvent_t ev_main = nullptr;                                          // main-stream position at prepare time
-  hipEvent_t ev_done[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-  bool done_recorded[NSLOT] = {false, false, false, false};
+  hipEvent_t ev_done[NSLOT] = {};
+  bool done_recorded[NSLOT] = {};
+  hipEvent_t ev_slot_main[NSLOT] = {};   // main-stream work of the layer step that last used the slot
+  bool slot_main_recorded[NSLOT] = {};
+  hipEvent_t ev_post_pos = nullptr;      // position of the side_post stream (parameter updates issued there)
+  hipEvent_t ev_post_tail = nullptr;     // last rgp_adam_step_post
+  bool post_tail_recorded = false;
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
   int num_cu = 256;
   // optional profiling of the psi2 launch (rgp_set_profiling)

@@ -17,6 +17,7 @@ rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg) {
 void rgp_join_streams(rgp_handle h) {
   for (int k = 0; k < rgp_ctx::NSLOT; ++k)
     if (h->done_recorded[k]) (void)hipStreamWaitEvent(h->stream, h->ev_done[k], 0);
+  if (h->post_tail_recorded) (void)hipStreamWaitEvent(h->stream, h->ev_post_tail, 0);
 }
 
 extern "C" rgp_status rgp_join(rgp_handle h) {
@@ -70,6 +71,8 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
       hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->side_rows, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_post_pos, hipEventDisableTiming);
+  hipEventCreateWithFlags(&h->ev_post_tail, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming);
   for (int k = 0; k < rgp_ctx::NSLOT; ++k) {
@@ -77,6 +80,7 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
     hipEventCreateWithFlags(&h->ev_pre_a[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_rows[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_pre_b[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_slot_main[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
   }
   *out = h;
@@ -592,6 +596,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.zt.M = M; L.zt.Q = Q; L.zt.QP = QP;
   L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP); L.zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.zt.zd = ws.take<double>((size_t)M * M); L.zt.Kuu = ws.take<double>((size_t)M * M);
+  if (ch) svi_chain_carve(*ch, ws);        // before anything sized by N: a chain-only prepare fixes these addresses
   L.rt.N = N; L.rt.QP = QP;
   L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq); L.rt.em = ws.take<double>(nq);
   L.rt.g0 = ws.take<double>(N); L.rt.g1 = ws.take<double>(N);
@@ -611,7 +616,6 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
   L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
-  if (ch) svi_chain_carve(*ch, ws);
   if (vc) {
     L.r2 = ws.take<double>(N); L.dYvar_row = ws.take<double>(N);
     L.PsiR_part = ws.take<double>((size_t)L.nblk1 * M * M); L.PsiR = ws.take<double>((size_t)M * M);
@@ -926,7 +930,10 @@ static rgp_status svi_check_args(rgp_handle h, const rgp_layer_in* in) {
 // Everything of a layer step that depends only on the parameters and the signals, not on the M x M chain: K_uu and the
 // chain's first stage (side stream), the window tables and the row terms (main stream).  rgp_layer_prepare issues this for
 // every layer before the first step, so the main stream has row work to do while the first chain runs.
-static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* slot_out) {
+// mode: 0 = chain + rows (new slot), 1 = chain only (new slot; ordered after the side_post stream, NOT after the main
+// stream: used right after a layer's parameter update while the main stream is still busy with later layers),
+// 2 = rows only (attaches to `*slot_out`, a slot prepared with mode 1).
+static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mode, int* slot_out) {
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
@@ -935,36 +942,55 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int* sl
   SviChain c{};
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
   const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, &c);
-  const int slot = h->slot_next;
-  h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
-  if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
+  int slot;
+  if (mode == 2) {
+    slot = *slot_out;
+    if (need > h->ws_slot_bytes[slot])
+      return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_prepare(rows): the minibatch is larger than the one of the chain-only prepare");
+  } else {
+    slot = h->slot_next;
+    h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
+    if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
+  }
   hipStream_t s = h->overlap ? h->side_rows : h->stream;      // everything below is off the main stream
   hipStream_t s_pre = h->overlap ? h->side_pre : s;
   if (h->overlap) {
-    // parameters and signals are written by main-stream work (the previous step's update), and the slot's previous user
-    // on the main stream must be finished too
-    RGP_HIP_CHECK(h, hipEventRecord(h->ev_main, h->stream));
-    RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_main, 0));
+    if (mode == 1) {
+      // the parameters were updated on the side_post stream (rgp_adam_step_post); the slot's previous users are covered
+      // by their own events, so the main stream's queue (later layers of the running step) is not waited for
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_post_pos, h->side_post));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_post_pos, 0));
+      if (h->slot_main_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_slot_main[slot], 0));
+    } else {
+      // parameters and signals are written by main-stream work (the previous step's update), and the slot's previous
+      // user on the main stream must be finished too
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_main, h->stream));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_main, 0));
+    }
   }
-  // the side-stream work that last used this slot must be finished before it is overwritten
-  if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
   carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
-  launch_prep_z(s, M, Q, L.zt.QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
-  c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
-  if (h->overlap) {
-    RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
-    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
+  if (mode != 2) {
+    // the side-stream work that last used this slot must be finished before it is overwritten
+    if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
+    launch_prep_z(s, M, Q, L.zt.QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+    c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
+    if (h->overlap) {
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
+    }
+    if ((st = launch_svi_chain_pre(h, c, s_pre, h->overlap ? h->ev_pre_a[slot] : nullptr, h->overlap ? h->ev_pre_b[slot] : nullptr))) return st;
+    if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   }
-  if ((st = launch_svi_chain_pre(h, c, s_pre, h->overlap ? h->ev_pre_a[slot] : nullptr, h->overlap ? h->ev_pre_b[slot] : nullptr))) return st;
-  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
-  // tables + rows
-  hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
-                     in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
-                     L.psi0sum, L.psi0coef);
-  const WindowSpec w = svi_window_spec(in, L);
-  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
-  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
-  if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_rows[slot], s));
+  if (mode != 1) {
+    // tables + rows
+    hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
+                       in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
+                       L.psi0sum, L.psi0coef);
+    const WindowSpec w = svi_window_spec(in, L);
+    launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+    launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+    if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_rows[slot], s));
+  }
   *slot_out = slot;
   return RGP_OK;
 }
@@ -986,12 +1012,41 @@ extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
   if (in->mode != RGP_MODE_SVI) return RGP_OK;
   rgp_status st = svi_check_args(h, in);
   if (st) return st;
+  const int flags = in->reserved & (RGP_PREPARE_CHAIN_ONLY | RGP_PREPARE_ROWS_ONLY);
+  if (flags == RGP_PREPARE_ROWS_ONLY) {
+    // attach the rows to the oldest prepared layer that has only its chain
+    for (int k = 0; k < h->prepared_count; ++k) {
+      const int e = (h->prepared_head + k) % rgp_ctx::NSLOT;
+      if (!h->prepared_rows[e]) {
+        int slot = h->prepared_slot[e];
+        if ((st = svi_prepare_slot(h, in, 2, &slot))) return st;
+        h->prepared_rows[e] = true;
+        return last_launch(h, "rgp_layer_prepare(rows)");
+      }
+    }
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_prepare(rows): no chain-only layer outstanding");
+  }
   if (h->prepared_count >= rgp_ctx::NSLOT - 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_prepare: too many layers outstanding");
   int slot;
-  if ((st = svi_prepare_slot(h, in, &slot))) return st;
-  h->prepared_slot[(h->prepared_head + h->prepared_count) % rgp_ctx::NSLOT] = slot;
+  if ((st = svi_prepare_slot(h, in, flags == RGP_PREPARE_CHAIN_ONLY ? 1 : 0, &slot))) return st;
+  const int e = (h->prepared_head + h->prepared_count) % rgp_ctx::NSLOT;
+  h->prepared_slot[e] = slot;
+  h->prepared_rows[e] = flags != RGP_PREPARE_CHAIN_ONLY;
   h->prepared_count++;
   return last_launch(h, "rgp_layer_prepare");
+}
+
+extern "C" rgp_status rgp_discard_prepared(rgp_handle h) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  h->prepared_count = 0;
+  h->prepared_head = 0;
+  return RGP_OK;
+}
+
+extern "C" rgp_status rgp_get_stream(rgp_handle h, int which, void** stream) {
+  if (!h || !stream) return RGP_ERR_BAD_ARG;
+  *stream = (void*)(which == 1 && h->overlap ? h->side_post : h->stream);
+  return RGP_OK;
 }
 
 extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
@@ -1010,12 +1065,14 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   hipStream_t s_post = h->overlap ? h->side_post : s;
   int slot;
   if (h->prepared_count > 0) {                       // K_uu + chain_pre already in flight (rgp_layer_prepare)
+    if (!h->prepared_rows[h->prepared_head])
+      return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: the prepared layer has no rows yet (call rgp_layer_prepare with RGP_PREPARE_ROWS_ONLY)");
     slot = h->prepared_slot[h->prepared_head];
     h->prepared_head = (h->prepared_head + 1) % rgp_ctx::NSLOT;
     h->prepared_count--;
     carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
   } else {
-    if ((st = svi_prepare_slot(h, in, &slot))) return st;
+    if ((st = svi_prepare_slot(h, in, 0, &slot))) return st;
     carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, &c);
   }
   c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
@@ -1096,6 +1153,8 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   }
   // data-dependent algebra + kernel-hyperparameter gradients on the side stream: overlaps the next layer's psi passes
   if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));
+    h->slot_main_recorded[slot] = true;
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre[slot], 0));
@@ -1139,6 +1198,21 @@ __global__ void __launch_bounds__(256) adam_kernel(int64_t n, double* __restrict
   const double xi = x[i] + lr * (mi / c1) / (sqrt(vi / c2) + eps);     // ascent on the ELBO
   x[i] = xi;
   p[i] = pos ? (xi > 36.0 ? xi : log1p(exp(xi))) : xi;
+}
+
+extern "C" rgp_status rgp_adam_step_post(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,
+                                         const uint8_t* positive, double lr, double beta1, double beta2, double eps,
+                                         int64_t step) {
+  if (!h || n <= 0) return RGP_ERR_BAD_ARG;
+  hipStream_t s = h->overlap ? h->side_post : h->stream;
+  const double c1 = 1.0 - pow(beta1, (double)step), c2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, p, g, m, v, positive, lr, beta1,
+                     beta2, eps, c1, c2);
+  if (h->overlap) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_post_tail, s));
+    h->post_tail_recorded = true;
+  }
+  return last_launch(h, "rgp_adam_step_post");
 }
 
 extern "C" rgp_status rgp_adam_step(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,

@@ -1517,7 +1517,8 @@ Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   Psi2Plan pl;
   const int nt = (fwd && bwd && !h->deterministic) ? psi2_packed_teams(M, QP) : 0;
   if (nt > 4) {
-    int64_t g = h->num_cu;                         // one 512-thread workgroup per CU, nt rows in flight
+    int64_t g = h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0);     // one 512-thread workgroup per CU, nt rows in flight;
+                                                                          // one CU stays free for the side-stream M x M chains
     if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
     pl.grid = (int)(g < 1 ? 1 : g);
     pl.n_p2 = pl.grid; pl.n_dz = pl.grid; pl.n_dl = nt * pl.grid;

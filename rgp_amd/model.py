@@ -16,6 +16,7 @@ mirror ``grad_array``:
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -224,6 +225,13 @@ class DeepAutoreg(object):
         self._adam = None
         self.data_streamer = None
         self.mb_inf_sample_idxes = None
+        # consecutive svi_step calls overlap the next step's M x M chains with the running step (see _svi_step_pipelined);
+        # every other way of changing parameters goes through _flush_pipeline first.  Code that writes param_array directly
+        # between svi_step calls must call params_changed().
+        self.pipeline = os.environ.get('RGP_NO_PIPELINE') is None
+        self._chain_ready = False
+        self._chain_n = None
+        self._post_stream = None
 
     # ------------------------------------------------------------------------------------------------------------
     # host-side helpers used only at construction (setup, not the hot path)
@@ -287,7 +295,13 @@ class DeepAutoreg(object):
         a, b, shp = L.slices[name]
         return (self.grad_array if grad else self.param_array)[a:b].view(*shp)
 
+    def params_changed(self):
+        """Call after writing ``param_array`` directly (paramz does this implicitly): invalidates work in flight."""
+        self._flush_pipeline()
+        self._adam = None
+
     def set_param(self, L, name, value):
+        self._flush_pipeline()
         v = torch.as_tensor(np.asarray(value, dtype=np.float64), device=self.device)
         self.view(L, name).copy_(v.reshape(self.view(L, name).shape))
 
@@ -326,6 +340,38 @@ class DeepAutoreg(object):
         scalar ELBO (also stored in ``grad_array[elbo_slot]``).  Latent gradients are written for the touched sequences
         only."""
         h = self.handle
+        self._flush_pipeline()
+        ios, n_batch = self._build_ios(seqs, qU_ratio)
+        # start K_uu / factorisations / the data-independent SVI algebra of every layer now (side stream): they need only
+        # the parameters, and would otherwise sit on the critical path in front of each layer's psi passes
+        if self.svi and len(ios) <= 3:
+            for lin, _ in ios:
+                h.layer_prepare(lin)
+        if (not self.svi) and stats_allreduce is not None:
+            # data-parallel collapsed bound: one all-reduce of the sufficient statistics per layer (svi_vardtc.py:65-67)
+            for (lin, lout), L in zip(ios, self.layers):
+                stats = torch.empty(2 + 2 * L.M * L.M + L.D * L.M, dtype=torch.float64, device=self.device)
+                ntot = torch.tensor([float(lin.N)], dtype=torch.float64, device=self.device)
+                h.vardtc_stats(lin, stats)
+                stats_allreduce(stats, ntot, L)
+                h.vardtc_finish(lin, lout, stats, int(round(float(ntot.item()))), 1.0 / world)
+        else:
+            for lin, lout in ios:
+                h.layer_step(lin, lout)
+        h.join()                         # global gradients / ELBO of every layer are produced on the library's side streams
+        elbo = self._elbo_buf.sum()
+        self.grad_array[self.elbo_slot] = elbo
+        self._last_n_batch = n_batch
+        return elbo
+
+    def _flush_pipeline(self):
+        """Drop the early chains a pipelined svi_step left in flight (the parameters may have been changed since)."""
+        if getattr(self, '_chain_ready', False):
+            self.handle.discard_prepared()
+            self._chain_ready = False
+
+    def _build_ios(self, seqs, qU_ratio):
+        """rgp_layer_in / rgp_layer_out of every layer (top first) for the sequences ``seqs``."""
         n_batch = None
         self._keep = []
         ios = []
@@ -367,27 +413,7 @@ class DeepAutoreg(object):
                 lout.g_up_mean, lout.g_up_var = self.gmeans.data_ptr(), self.gvars.data_ptr()
             lout.woodbury_inv, lout.woodbury_vector = self._winv[i].data_ptr(), self._wvec[i].data_ptr()
             ios.append((lin, lout))
-        # start K_uu / factorisations / the data-independent SVI algebra of every layer now (side stream): they need only
-        # the parameters, and would otherwise sit on the critical path in front of each layer's psi passes
-        if self.svi and len(ios) <= 3:
-            for lin, _ in ios:
-                h.layer_prepare(lin)
-        if (not self.svi) and stats_allreduce is not None:
-            # data-parallel collapsed bound: one all-reduce of the sufficient statistics per layer (svi_vardtc.py:65-67)
-            for (lin, lout), L in zip(ios, self.layers):
-                stats = torch.empty(2 + 2 * L.M * L.M + L.D * L.M, dtype=torch.float64, device=self.device)
-                ntot = torch.tensor([float(lin.N)], dtype=torch.float64, device=self.device)
-                h.vardtc_stats(lin, stats)
-                stats_allreduce(stats, ntot, L)
-                h.vardtc_finish(lin, lout, stats, int(round(float(ntot.item()))), 1.0 / world)
-        else:
-            for lin, lout in ios:
-                h.layer_step(lin, lout)
-        h.join()                         # global gradients / ELBO of every layer are produced on the library's side streams
-        elbo = self._elbo_buf.sum()
-        self.grad_array[self.elbo_slot] = elbo
-        self._last_n_batch = n_batch
-        return elbo
+        return ios, n_batch
 
     def log_likelihood(self, seqs=None):
         e = float(self.evaluate(seqs).item())
@@ -416,6 +442,7 @@ class DeepAutoreg(object):
         return torch.where(pos, _softplus_inv(p), p).cpu().numpy()
 
     def set_optimizer_array(self, x, seqs=None):
+        self._flush_pipeline()
         idx = self._index_set(seqs)
         x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=self.device)
         pos = self.positive[idx].bool()
@@ -479,6 +506,7 @@ class DeepAutoreg(object):
     def load(self, path):
         d = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
         assert int(d['n_global']) == self.n_global and int(d['n_local']) == self.n_local, 'parameter layout mismatch'
+        self._flush_pipeline()
         self.param_array.copy_(torch.as_tensor(d['param_array'], device=self.device))
         self._adam = None
 
@@ -497,16 +525,20 @@ class DeepAutoreg(object):
         if self._adam is None:
             self._init_adam()
         ad, h = self._adam, self.handle
-        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
-        if allreduce is not None:
-            allreduce(self.grad_array[:self.n_global + 1])
-            elbo = self.grad_array[self.elbo_slot]
-        if not update:              # debugging / kernel ablations only
-            return elbo
-        ad['t_glob'] += 1
-        G = self.n_global
-        h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
-                    self.positive[:G], lr, ad['t_glob'])
+        pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate
+        if pipelined:
+            elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio)
+        else:
+            elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+            if allreduce is not None:
+                allreduce(self.grad_array[:self.n_global + 1])
+                elbo = self.grad_array[self.elbo_slot]
+            if not update:              # debugging / kernel ablations only
+                return elbo
+            ad['t_glob'] += 1
+            G = self.n_global
+            h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
+                        self.positive[:G], lr, ad['t_glob'])
         if isinstance(seqs, slice):
             ranges = [(seqs.start or 0, seqs.stop if seqs.stop is not None else self.nSeq)]
         elif seqs is None:
@@ -521,6 +553,42 @@ class DeepAutoreg(object):
                 sl = slice(base + a, base + b)
                 h.adam_step(self.opt_array[sl], self.param_array[sl], self.grad_array[sl], ad['m'][sl], ad['v'][sl],
                             self.positive[sl], lr, t)
+        return elbo
+
+    def _svi_step_pipelined(self, seqs, lr, allreduce, qU_ratio):
+        """ELBO + gradients + update of the GLOBAL parameters, layer by layer: as soon as a layer's gradients exist (library
+        side stream) they are all-reduced and applied there, and the M x M chain of the NEXT step is started for that layer
+        while the main stream is still busy with the psi passes of the layers below (include/rgp_hip.h, pipelining
+        section).  Same arithmetic as evaluate + one Adam step; only the order of independent work changes."""
+        from ._lib import PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY
+        ad, h = self._adam, self.handle
+        ios, n_batch = self._build_ios(seqs, qU_ratio)
+        n_prev = getattr(self, '_chain_n', None)
+        if self._chain_ready and n_prev is not None and any(lin.N > n for (lin, _), n in zip(ios, n_prev)):
+            self._flush_pipeline()                      # larger minibatch than the early chains were sized for
+        for lin, _ in ios:
+            h.layer_prepare(lin, PREPARE_ROWS_ONLY if self._chain_ready else 0)
+        ad['t_glob'] += 1
+        if allreduce is not None and self._post_stream is None:
+            self._post_stream = torch.cuda.ExternalStream(h.get_stream(1), device=self.device)
+        for (lin, lout), L in zip(ios, self.layers):
+            h.layer_step(lin, lout)
+            a = min(v[0] for v in L.slices.values())
+            b = max(v[1] for v in L.slices.values())
+            if allreduce is not None:
+                with torch.cuda.stream(self._post_stream):
+                    allreduce(self.grad_array[a:b])
+            h.adam_step(self.opt_array[a:b], self.param_array[a:b], self.grad_array[a:b], ad['m'][a:b], ad['v'][a:b],
+                        self.positive[a:b], lr, ad['t_glob'], post=True)
+            h.layer_prepare(lin, PREPARE_CHAIN_ONLY)
+        self._chain_ready = True
+        self._chain_n = [lin.N for lin, _ in ios]
+        h.join()
+        elbo = self._elbo_buf.sum()
+        if allreduce is not None:
+            allreduce(elbo)
+        self.grad_array[self.elbo_slot] = elbo
+        self._last_n_batch = n_batch
         return elbo
 
     # ------------------------------------------------------------------------------------------------------------
