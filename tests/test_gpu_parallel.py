@@ -1,0 +1,72 @@
+"""Data-parallel SVI on the HIP path with world_size 2 (both ranks share the one GPU of the test box, gloo moves the device
+buckets): sequence shards + local qU_ratio + per-layer all-reduce inside the pipelined svi_step reproduce the global
+parameters of a single-process run on the union minibatch, step after step (bench.py's multi-GPU path with RCCL does the same
+calls)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_model import make_data
+
+WINS, NDIMS, UWIN, M, NTOT, T, STEPS = [0, 3, 3], [3, 2, 3], 2, 4, 4, 14, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _model(Y, U):
+    from rgp_amd.model import DeepAutoreg
+    return DeepAutoreg(WINS, Y, U=U, U_win=UWIN, nDims=NDIMS, X_variance=0.05, num_inducing=M, init='Y',
+                       inference_method='svi', mb_inf_tot_data_size=NTOT, seed=3)
+
+
+def _globals0():
+    """Identical starting globals for every process (q(U) initialisation depends on the local data otherwise)."""
+    U, Y = make_data(NTOT, T, seed=0)
+    return _model(Y, U).param_array[:_model(Y, U).n_global].clone()
+
+
+def _worker(rank, world, port, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from rgp_amd import parallel
+    U, Y = make_data(NTOT, T, seed=0)
+    full = _model(Y, U)
+    a, b = parallel.shard_range(NTOT, world, rank)
+    m = _model(Y[a:b], U[a:b])
+    m.param_array[:m.n_global].copy_(full.param_array[:full.n_global])
+    m.params_changed()
+    allreduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    elbos = []
+    for k in range(STEPS):
+        e = m.svi_step(slice(0, b - a), lr=1e-2, allreduce=allreduce, qU_ratio=float(NTOT) / NTOT / world)
+        elbos.append(float(e.item()))
+    m.handle.sync()
+    if rank == 0:
+        np.savez(out_path, g=m.param_array[:m.n_global].cpu().numpy(), e=np.array(elbos))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_track_the_single_process_run(tmp_path):
+    out = str(tmp_path / 'dp.npz')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    U, Y = make_data(NTOT, T, seed=0)
+    m = _model(Y, U)
+    elbos = []
+    for k in range(STEPS):
+        elbos.append(float(m.svi_step(slice(0, NTOT), lr=1e-2).item()))
+    m.handle.sync()
+    np.testing.assert_allclose(got['e'], np.array(elbos), rtol=1e-10)
+    np.testing.assert_allclose(got['g'], m.param_array[:m.n_global].cpu().numpy(), rtol=1e-8, atol=1e-10)
