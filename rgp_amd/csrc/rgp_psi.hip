@@ -1232,16 +1232,15 @@ template <int QP>
 static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
                                                      double& v, const double base, const double hbm, const double dlv,
                                                      double* __restrict__ p2slot, const bool own, const double* __restrict__ etab) {
-  double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+  // dzl carries the factor -1/2, and the first chain starts from the (row, m) + (row, m') constant: E is one add away.
+  // Two chains are enough: a dependent v_fma_f64 issues every ~6 cycles from one wave (profiles/r1_f64_lat.txt).
+  double c0 = base + hbm, c1 = 0.0;
 #pragma unroll
-  for (int q = 0; q < QP; q += 4) {
+  for (int q = 0; q < QP; q += 2) {
     c0 += dzl[q] * zs[q];
     c1 += dzl[q + 1] * zs[q + 1];
-    c2 += dzl[q + 2] * zs[q + 2];
-    c3 += dzl[q + 3] * zs[q + 3];
   }
-  const double E = (base + hbm) - 0.5 * ((c0 + c1) + (c2 + c3));
-  const double p = exp_tab(E, etab);
+  const double p = exp_tab(c0 + c1, etab);
   if (own) atomicAdd(p2slot, p);          // ds_add_f64, no return
   const double w = p * dlv;
   v += w;
@@ -1347,8 +1346,8 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     for (int q = 0; q < QP; q += 2) {
       const double z0 = zrow(q), z1 = zrow(q + 1);
       const double d0 = rd[q], d1 = rd[q + 1];
-      dzl[q] = z0 * (d0 - lam_g[q]);
-      dzl[q + 1] = z1 * (d1 - lam_g[q + 1]);
+      dzl[q] = -0.5 * z0 * (d0 - lam_g[q]);
+      dzl[q + 1] = -0.5 * z1 * (d1 - lam_g[q + 1]);
       h0 += z0 * d0 * (rd[QP + q] - 0.25 * z0);
       h1 += z1 * d1 * (rd[QP + q + 1] - 0.25 * z1);
     }
