@@ -17,12 +17,12 @@
 #include <stdlib.h>
 
 // exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
-// n = rint(x * 64/ln2) = 64 k + j, r = x - n ln2/64 (|r| <= ln2/128) and q the degree-5 Taylor polynomial of expm1 (next term
-// r^6/720 < 4e-17).  T[j] = 2^(j/64) is a 64-entry LDS table.  15 VALU instructions and one LDS read instead of the ~36
-// (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp (the
-// rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register sources:
-// the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
-#define PSI2_EXP_TAB 64
+// n = rint(x * 256/ln2) = 256 k + j, r = x - n ln2/256 (|r| <= ln2/512) and q the degree-4 Taylor polynomial of expm1 (next
+// term r^5/120 < 4e-17).  T[j] = 2^(j/256) is a 256-entry LDS table (2 KB).  14 VALU instructions and one LDS read instead of
+// the ~36 (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp
+// (the rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register
+// sources: the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
+#define PSI2_EXP_TAB 256
 static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -30,18 +30,17 @@ static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
 }
 static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
   x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
-  const double t = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);          // 64/ln2; integer n in the low mantissa bits
+  const double t = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);          // 256/ln2; integer n in the low mantissa bits
   const int n = __double2loint(t);
   const double nf = t - 0x1.8p52;
-  double r = fma(nf, -0x1.62e42fefa0000p-7, x);                     // ln2/64 split: high part has 33 significant bits
-  r = fma(nf, -0x1.cf79abc9e3b3ap-46, r);
+  double r = fma(nf, -0x1.62e42fee00000p-9, x);                     // ln2/256 split: the high part has 32 significant bits
+  r = fma(nf, -0x1.a39ef35793c76p-41, r);
   const double tj = T[n & (PSI2_EXP_TAB - 1)];
-  double q = fma_rrr(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);      // 1/120, 1/24
-  q = fma_rrr(q, r, 0x1.5555555555555p-3);                                 // 1/6
+  double q = fma_rrr(r, 0x1.5555555555555p-5, 0x1.5555555555555p-3);       // 1/24, 1/6
   q = fma_rrr(q, r, 0.5);
   q = fma_rrr(q, r, 1.0);
   q = q * r;
-  return ldexp(fma(tj, q, tj), n >> 6);
+  return ldexp(fma(tj, q, tj), n >> 8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1272,7 +1271,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
   double* rowd = hbuf + PSI2_MAX_NT * RGP_PSI2_TEAM;      // [NT x RD]
   double* red = rowd + PSI2_MAX_NT * RD;                  // [8 waves x RED_WAVE]
   double* res = red + 8 * RED_WAVE;                       // [8 waves x 2 x RW]
-  double* etab = res + 8 * 2 * RW;                        // [64] 2^(j/64)
+  double* etab = res + 8 * 2 * RW;                        // [256] 2^(j/256)
 #ifdef PSI2_STAMPS
   long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, tG = 0, tH = 0, t0 = 0, t1;
 #endif
@@ -1490,7 +1489,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
 static size_t psi2_rowsN_lds(int M, int QP) {
   const size_t tri = (size_t)M * (M + 1) / 2;
   return (tri + (size_t)QP * RGP_PSI2_TEAM + PSI2_MAX_NT * RGP_PSI2_TEAM + PSI2_MAX_NT * (2 * (size_t)QP + 2) +
-          8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8) + 64) * sizeof(double);
+          8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8) + PSI2_EXP_TAB) * sizeof(double);
 }
 
 // number of packed teams (0: use the four-team / two-team kernels)
