@@ -79,6 +79,7 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
     hipEventCreateWithFlags(&h->ev_pre[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_pre_a[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_rows[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_yry[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_pre_b[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_slot_main[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
@@ -988,8 +989,9 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
                        L.psi0sum, L.psi0coef);
     const WindowSpec w = svi_window_spec(in, L);
     launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
-    launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
     if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_rows[slot], s));
+    launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);          // only the chain's last stage reads it
+    if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_yry[slot], s));
   }
   *slot_out = slot;
   return RGP_OK;
@@ -1158,6 +1160,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre[slot], 0));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_yry[slot], 0));
   }
   if ((st = launch_svi_chain_post(h, c, s_post))) return st;
   {
