@@ -541,45 +541,48 @@ psi1_svi_fwd_kernel(const int64_t N, const int M, const int D, const double* __r
   }
 }
 
-template <int QP>
+// pass F with two inducing rows per lane (m, m + 64): one wave covers all M <= 128 rows of a data row, the four waves of
+// the workgroup take different data rows of the tile, and each broadcast ds_read_b128 of (e, e*mu) feeds four multiply-adds
+// instead of two (the one-row version is bound by those reads).  Used when the D-sized register arrays are small (DP <= 4).
+template <int QP, int DP>
 __global__ void __launch_bounds__(256, 2)
-psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
-                   const double* __restrict__ em, const double* __restrict__ Lp, double* __restrict__ dz_part) {
-  constexpr int EE = P1_TILE * QP;
-  constexpr int CB = QP * RGP_PSI2_TEAM;
+psi1_svi_fwd2_kernel(const int64_t N, const int M, const int D, const double* __restrict__ Zc, const double* __restrict__ e1,
+                     const double* __restrict__ em, const double* __restrict__ g1, const double* __restrict__ Ym,
+                     const double* __restrict__ Cpsi1, double* __restrict__ P, double* __restrict__ Lp,
+                     double* __restrict__ psi1Y_part) {
+  constexpr int EE = P1_TILE * QP;                                  // double2 entries
+  constexpr int CB = 3 * DP * RGP_PSI2_TEAM;                        // doubles needed to combine the four waves
   constexpr int NB = (2 * EE > CB) ? 2 * EE : CB;
   __shared__ __attribute__((aligned(16))) double buf[NB];
-  __shared__ double lt[(P1_TILE / 2) * 256];
+  __shared__ double ys[P1_TILE * DP];
+  __shared__ double gs[P1_TILE];
+  __shared__ double etab[PSI2_EXP_TAB];
   double2* ee = reinterpret_cast<double2*>(buf);
-  const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1), team = t >> 7;
-  const bool act = tr < M;
-  const int tm = act ? tr : M - 1;
-  double z[QP], acc[QP];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
+  const int m0 = lane, m1 = lane + 64;
+  const bool act0 = m0 < M, act1 = m1 < M;
+  const int c0 = act0 ? m0 : M - 1, c1 = act1 ? m1 : M - 1;
+  double z0[QP], z1[QP], cA[DP], cB[DP], pyA[DP], pyB[DP];
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
-    z[q] = Zc[(size_t)tm * QP + q];
-    acc[q] = 0.0;
+    z0[q] = Zc[(size_t)c0 * QP + q];
+    z1[q] = Zc[(size_t)c1 * QP + q];
+  }
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    cA[d] = d < D ? Cpsi1[(size_t)c0 * D + d] : 0.0;
+    cB[d] = d < D ? Cpsi1[(size_t)c1 * D + d] : 0.0;
+    pyA[d] = 0.0;
+    pyB[d] = 0.0;
   }
   const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
   const int64_t r0 = (int64_t)blockIdx.x * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
   for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
     const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
-    // this thread's Lp values of the tile are parked in a private LDS column (loaded and consumed by the same thread)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      double lv[P1_TILE / 4];
-#pragma unroll
-      for (int k = 0; k < P1_TILE / 4; ++k) {
-        const int r = team + 2 * (k + h * (P1_TILE / 4));
-        lv[k] = Lp[(rb + (r < nr ? r : nr - 1)) * M + tm];
-      }
-#pragma unroll
-      for (int k = 0; k < P1_TILE / 4; ++k) {
-        const int r = team + 2 * (k + h * (P1_TILE / 4));
-        lt[(k + h * (P1_TILE / 4)) * 256 + t] = (act && r < nr) ? lv[k] : 0.0;
-      }
-    }
+    __syncthreads();
     {
       const int64_t lim = (int64_t)nr * QP - 1;
       double2 v[QP / 8];
@@ -588,34 +591,141 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
         const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
         v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
       }
-      __syncthreads();
+      const int yr = (t / DP < nr) ? t / DP : nr - 1, yd = t % DP;
+      const double yv = (t < P1_TILE * DP && yd < D) ? Ym[(rb + yr) * D + (yd < D ? yd : 0)] : 0.0;
+      const double gv = g1[rb + (t < nr ? t : nr - 1)];
 #pragma unroll
       for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+      if (t < P1_TILE * DP) ys[t] = yv;
+      if (t < P1_TILE) gs[t] = gv;
     }
     __syncthreads();
+#pragma unroll 1
+    for (int r = wave; r < nr; r += 4) {
+      const double2* er = ee + r * QP;
+      double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < P1_TILE / 2; ++k) {
-      const int r = team + 2 * k;
-      if (r < nr) {
-        const double2* er = ee + r * QP;
-        const double lp = lt[k * 256 + t];
+      for (int q = 0; q < QP; ++q) {
+        const double2 x = er[q];
+        a0 += z0[q] * (x.x * z0[q] - 2.0 * x.y);
+        a1 += z1[q] * (x.x * z1[q] - 2.0 * x.y);
+      }
+      const double g = gs[r];
+      const double p0 = exp_tab(g - 0.5 * a0, etab), p1 = exp_tab(g - 0.5 * a1, etab);
+      double dl0 = 0.0, dl1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < QP; ++q) {
-          const double2 x = er[q];
-          acc[q] += lp * (x.y - x.x * z[q]);
-        }
+      for (int d = 0; d < DP; ++d) {
+        const double y = ys[r * DP + d];
+        dl0 += y * cA[d];
+        dl1 += y * cB[d];
+        pyA[d] += y * p0;
+        pyB[d] += y * p1;
+      }
+      if (act0) {
+        Lp[(rb + r) * M + m0] = dl0 * p0;
+        if (P) P[(rb + r) * M + m0] = p0;
+      }
+      if (act1) {
+        Lp[(rb + r) * M + m1] = dl1 * p1;
+        if (P) P[(rb + r) * M + m1] = p1;
       }
     }
   }
+  // psi1Y partial of this workgroup: wave 0 + 1 + 2 + 3 (fixed order)
   __syncthreads();
-  if (team == 1) {
+  if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < QP; ++q) buf[q * RGP_PSI2_TEAM + tr] = acc[q];
+    for (int d = 0; d < DP; ++d) {
+      buf[((wave - 1) * DP + d) * RGP_PSI2_TEAM + m0] = pyA[d];
+      buf[((wave - 1) * DP + d) * RGP_PSI2_TEAM + m1] = pyB[d];
+    }
   }
   __syncthreads();
-  if (team == 0 && act) {
+  if (wave == 0) {
 #pragma unroll
-    for (int q = 0; q < QP; ++q) dz_part[((size_t)blockIdx.x * M + tr) * QP + q] = acc[q] + buf[q * RGP_PSI2_TEAM + tr];
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        double sA = pyA[d], sB = pyB[d];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          sA += buf[(w * DP + d) * RGP_PSI2_TEAM + m0];
+          sB += buf[(w * DP + d) * RGP_PSI2_TEAM + m1];
+        }
+        if (act0) psi1Y_part[((size_t)blockIdx.x * D + d) * M + m0] = sA;
+        if (act1) psi1Y_part[((size_t)blockIdx.x * D + d) * M + m1] = sB;
+      }
+    }
+  }
+}
+
+// pass Z.  Lane = two inducing rows (m, m + 64), wave = one quarter of the q columns; all four waves walk all rows of the
+// tile.  One broadcast ds_read_b128 of (e, e*mu)[row, q] then feeds four multiply-adds instead of two, and a (m, q) slot has
+// exactly one owner, so nothing is combined at the end.  The Lp tile is staged in LDS (coalesced 128-column rows).
+template <int QP>
+__global__ void __launch_bounds__(256)
+psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
+                   const double* __restrict__ em, const double* __restrict__ Lp, double* __restrict__ dz_part) {
+  constexpr int QW = QP / 4;                               // QP is a multiple of 8
+  __shared__ __attribute__((aligned(16))) double buf[2 * P1_TILE * QP];
+  __shared__ double lps[P1_TILE * RGP_PSI2_TEAM];
+  double2* ee = reinterpret_cast<double2*>(buf);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q0 = wave * QW;
+  const int m0 = lane, m1 = lane + 64;
+  const int c0 = m0 < M ? m0 : M - 1, c1 = m1 < M ? m1 : M - 1;
+  double z0[QW], z1[QW], a0[QW], a1[QW];
+#pragma unroll
+  for (int j = 0; j < QW; ++j) {
+    z0[j] = Zc[(size_t)c0 * QP + q0 + j];
+    z1[j] = Zc[(size_t)c1 * QP + q0 + j];
+    a0[j] = 0.0;
+    a1[j] = 0.0;
+  }
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
+    const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
+    {
+      const int64_t lim = (int64_t)nr * QP - 1;
+      double2 v[QP / 8];
+      double lv[P1_TILE * RGP_PSI2_TEAM / 256];
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) {
+        const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
+        v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
+      }
+#pragma unroll
+      for (int k = 0; k < P1_TILE * RGP_PSI2_TEAM / 256; ++k) {
+        const int i = t + 256 * k, row = i >> 7, col = i & 127;
+        const bool ok = row < nr && col < M;
+        const double x = Lp[(rb + (ok ? row : 0)) * M + (ok ? col : 0)];
+        lv[k] = ok ? x : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+#pragma unroll
+      for (int k = 0; k < P1_TILE * RGP_PSI2_TEAM / 256; ++k) lps[t + 256 * k] = lv[k];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int r = 0; r < nr; ++r) {
+      const double2* er = ee + r * QP + q0;
+      const double l0 = lps[r * RGP_PSI2_TEAM + m0], l1 = lps[r * RGP_PSI2_TEAM + m1];
+#pragma unroll
+      for (int j = 0; j < QW; ++j) {
+        const double2 x = er[j];
+        a0[j] += l0 * (x.y - x.x * z0[j]);
+        a1[j] += l1 * (x.y - x.x * z1[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < QW; ++j) {
+    if (m0 < M) dz_part[((size_t)blockIdx.x * M + m0) * QP + q0 + j] = a0[j];
+    if (m1 < M) dz_part[((size_t)blockIdx.x * M + m1) * QP + q0 + j] = a1[j];
   }
 }
 
@@ -772,8 +882,12 @@ static void psi1_svi_dispatch(hipStream_t s, int64_t N, int M, int Q, int D, con
                               const double* Ym, const double* Cpsi1, const double* noise, double* P, double* Lp,
                               double* psi1Y_part, double* gmu, double* gS, double* dYm, double* dlam_part,
                               double* lsum_part, double* dz_part, int nblk) {
-  hipLaunchKernelGGL((psi1_svi_fwd_kernel<QP, DP>), dim3(nblk), dim3(256), 0, s, N, M, D, zt.Zc, rt.e1, rt.em, rt.g1, Ym,
-                     Cpsi1, dYm ? P : nullptr, Lp, psi1Y_part);
+  if (DP <= 4)
+    hipLaunchKernelGGL((psi1_svi_fwd2_kernel<QP, (DP <= 4 ? DP : 1)>), dim3(nblk), dim3(256), 0, s, N, M, D, zt.Zc, rt.e1,
+                       rt.em, rt.g1, Ym, Cpsi1, dYm ? P : nullptr, Lp, psi1Y_part);
+  else
+    hipLaunchKernelGGL((psi1_svi_fwd_kernel<QP, DP>), dim3(nblk), dim3(256), 0, s, N, M, D, zt.Zc, rt.e1, rt.em, rt.g1, Ym,
+                       Cpsi1, dYm ? P : nullptr, Lp, psi1Y_part);
   const int rb = psi1_svi_rows_blocks(N);
   if (dYm)
     hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, DP, true>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
