@@ -938,7 +938,7 @@ struct Psi2Args {
 template <int QP, bool FWD, bool BWD>
 static __device__ __forceinline__ void psi2_pair(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
                                                  double& v, const double base, const double hbm, const double dlv,
-                                                 double* __restrict__ p2slot) {
+                                                 double* __restrict__ p2slot, const double* __restrict__ etab) {
   double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
 #pragma unroll
   for (int q = 0; q < QP; q += 4) {
@@ -948,7 +948,7 @@ static __device__ __forceinline__ void psi2_pair(const double* __restrict__ zs, 
     c3 += dzl[q + 3] * zs[q + 3];
   }
   const double E = (base + hbm) - 0.5 * ((c0 + c1) + (c2 + c3));
-  const double p = exp(E);
+  const double p = exp_tab(E, etab);
   if (FWD) atomicAdd(p2slot, p);          // ds_add_f64, no return: the slot has exactly one owner thread -> deterministic
   if (BWD) {
     const double w = p * dlv;
@@ -965,7 +965,7 @@ static __device__ __forceinline__ void psi2_sweep(const int a, const int b, cons
                                                   const double* __restrict__ dlrow, const int M, const double (&dzl)[QP],
                                                   double (&y)[QP], double& v, const double base,
                                                   const double* __restrict__ hb, double* __restrict__ p2acc, const int tri,
-                                                  const int tr, const bool act) {
+                                                  const int tr, const bool act, const double* __restrict__ etab) {
   if (a >= b) return;
   const int last = b - 1;
   double dlA = BWD ? dlrow[(size_t)a * M] : 0.0;
@@ -980,12 +980,12 @@ static __device__ __forceinline__ void psi2_sweep(const int a, const int b, cons
     {
       const bool own = act && mpa >= tr;
       psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpa * QP, dzl, y, v, base, hb[mpa], dla,
-                              p2acc + (own ? mpa * (mpa + 1) / 2 + tr : tri + tr));
+                              p2acc + (own ? mpa * (mpa + 1) / 2 + tr : tri + tr), etab);
     }
     if (mp + 1 < b) {
       const bool own = act && mpb >= tr;
       psi2_pair<QP, FWD, BWD>(Zc + (size_t)mpb * QP, dzl, y, v, base, hb[mpb], dlb,
-                              p2acc + (own ? mpb * (mpb + 1) / 2 + tr : tri + tr));
+                              p2acc + (own ? mpb * (mpb + 1) / 2 + tr : tri + tr), etab);
     }
   }
 }
@@ -1013,6 +1013,8 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
   double* hbuf = lds + (FWD ? tri + RGP_PSI2_TEAM : 0);  // [2 teams x 128]
   double* red = hbuf + 2 * RGP_PSI2_TEAM;                // [4 waves x RED_WAVE]          (BWD)
   double* res = red + (BWD ? 4 * RED_WAVE : 0);          // [4 waves x (2*QP + 8)]        (BWD)
+  __shared__ double etab[PSI2_EXP_TAB];
+  if (threadIdx.x < PSI2_EXP_TAB) etab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / PSI2_EXP_TAB));
 
   const int t = threadIdx.x;
   const int tr = t & (RGP_PSI2_TEAM - 1);                // inducing row owned by this thread
@@ -1071,9 +1073,9 @@ psi2_rows_kernel(const int64_t N, const int M, const int Q, const double* __rest
       for (int q = 0; q < QP; ++q) y[q] = 0.0;
     }
     // phase 1: team 0 sweeps [0, Mh), team 1 sweeps [Mh, M);  phase 2: swapped
-    psi2_sweep<QP, FWD, BWD>(team ? Mh : 0, team ? M : Mh, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
+    psi2_sweep<QP, FWD, BWD>(team ? Mh : 0, team ? M : Mh, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act, etab);
     if (FWD) __syncthreads();
-    psi2_sweep<QP, FWD, BWD>(team ? 0 : Mh, team ? Mh : M, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
+    psi2_sweep<QP, FWD, BWD>(team ? 0 : Mh, team ? Mh : M, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act, etab);
 
     if (BWD) {
       asm volatile("" ::: "memory");
@@ -1183,6 +1185,8 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
   double* hbuf = dzacc + QP * RGP_PSI2_TEAM;             // [4 teams x 128]
   double* red = hbuf + 4 * RGP_PSI2_TEAM;                // [8 waves x RED_WAVE]
   double* res = red + 8 * RED_WAVE;                      // [8 waves x (2*QP + 8)]
+  __shared__ double etab[PSI2_EXP_TAB];
+  if (threadIdx.x < PSI2_EXP_TAB) etab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / PSI2_EXP_TAB));
 
   const int t = threadIdx.x;
   const int tr = t & (RGP_PSI2_TEAM - 1);
@@ -1235,7 +1239,7 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
     for (int ph = 0; ph < 4; ++ph) {
       const int rq = (team + ph) & 3;
       const int a = rq * Mq, b = (a + Mq < M) ? a + Mq : M;
-      psi2_sweep<QP, true, true>(a, b, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act);
+      psi2_sweep<QP, true, true>(a, b, Zc, dlrow, M, dzl, y, v, base, hb, p2acc, tri, tr, act, etab);
       if (ph < 3) __syncthreads();
     }
 
@@ -1617,7 +1621,8 @@ int psi2_packed_teams(int M, int QP) {
 // LDS bytes of the four-team kernel
 static size_t psi2_rows4_lds(int M, int QP) {
   const size_t tri = (size_t)M * (M + 1) / 2;
-  return (tri + RGP_PSI2_TEAM + (size_t)QP * RGP_PSI2_TEAM + 4 * RGP_PSI2_TEAM + 8 * RED_WAVE + 8 * (2 * (size_t)QP + 8)) * sizeof(double);
+  return (tri + RGP_PSI2_TEAM + (size_t)QP * RGP_PSI2_TEAM + 4 * RGP_PSI2_TEAM + 8 * RED_WAVE + 8 * (2 * (size_t)QP + 8) +
+          PSI2_EXP_TAB /* static table */) * sizeof(double);
 }
 
 bool psi2_use_rows4(int M, int QP) {
