@@ -361,3 +361,26 @@ def test_deterministic_mode_is_bit_reproducible():
     G3 = g.grad_array.clone()
     assert abs(e3 - e1) <= 1e-12 * abs(e1)
     assert float((G3 - G1).abs().max()) <= 1e-10 * float(G1.abs().max())
+
+
+def test_pipelined_svi_steps_equal_plain_steps():
+    """svi_step overlaps the next step's M x M chains with the running step and updates each layer's global parameters on the
+    side stream (DeepAutoreg._svi_step_pipelined); the parameters after several steps must equal those of the plain
+    evaluate -> Adam sequence, and evaluate / set_param in between must see consistent state."""
+    _, a = build_pair(n_seq=4, T=40, M=6, seed=5, n_total=4)
+    _, b = build_pair(n_seq=4, T=40, M=6, seed=5, n_total=4)
+    b.pipeline = False
+    for k in range(4):
+        mb = slice(0, 2) if k % 2 == 0 else slice(2, 4)
+        ea = float(a.svi_step(mb, lr=2e-2).item())
+        eb = float(b.svi_step(mb, lr=2e-2).item())
+        assert abs(ea - eb) <= 1e-11 * abs(eb), (k, ea, eb)
+    ea = float(a.evaluate().item()); eb = float(b.evaluate().item())      # flushes the chains left in flight
+    a.handle.sync(); b.handle.sync()
+    assert abs(ea - eb) <= 1e-11 * abs(eb)
+    assert float((a.param_array - b.param_array).abs().max()) <= 1e-11 * float(b.param_array.abs().max())
+    L = a.layers[0]
+    a.set_param(L, 'noise', 0.123); b.set_param(L, 'noise', 0.123)         # a parameter change between pipelined steps
+    ea = float(a.svi_step(slice(0, 4), lr=1e-2).item()); eb = float(b.svi_step(slice(0, 4), lr=1e-2).item())
+    a.handle.sync(); b.handle.sync()
+    assert abs(ea - eb) <= 1e-11 * abs(eb)
