@@ -113,7 +113,7 @@ rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches
 /* Summation order of the psi2 forward statistic.  By default (on = 0) workgroups of the fused psi2 pass keep several data
  * rows in flight and add their terms to a shared fp64 accumulator in hardware order: results are reproducible to ~1 ulp
  * of each entry, not bit for bit.  on = 1 selects the rotating-team kernel whose additions happen in a fixed order
- * (bit-reproducible run to run, ~15% slower at M = 100).  The environment variable RGP_PSI2_NO_PACKED=1 has the same effect. */
+ * (bit-reproducible run to run, ~23% slower at M = 100).  The environment variable RGP_PSI2_NO_PACKED=1 has the same effect. */
 rgp_status rgp_set_deterministic(rgp_handle h, int on);
 
 /* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,

@@ -1331,9 +1331,9 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 #undef zrow
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused forward + backward pass with PACKED teams, for 64 <= M <= 102: the 512 threads of a workgroup are split into
-// NT = 512 / M teams of exactly M threads (M = 100: 5 rows in flight, 500 of 512 lanes busy instead of 400), so a wave
-// holds lanes of up to two data rows.  What keeps that cheap:
+// Fused forward + backward pass with PACKED teams: the 512 threads of a workgroup are split into NT = 512 / TS teams with
+// team stride TS = max(M, 64) (M = 100: 5 rows in flight, 500 of 512 lanes busy instead of 400 with 128-lane teams; M = 50:
+// 8 rows; M = 128: 4), so a wave holds lanes of up to two data rows.  What keeps that cheap:
 //   * all threads sweep m' in the same order, so z[m',:] stays a scalar operand for mixed waves too;
 //   * the forward sums are LDS fp64 atomics (ds_add_f64) from all teams, no rotation and no barriers inside the sweep.
 //     The NT adds a slot receives per iteration arrive in hardware order, so the last bits of psi2 can differ from run to
@@ -1373,7 +1373,7 @@ static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ 
 
 template <int QP>
 __global__ void __launch_bounds__(PSI2_T4, 2)
-psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const double* __restrict__ Zc,
+psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const int TS, const double* __restrict__ Zc,
                   const double* __restrict__ lam_g, const double* __restrict__ dLs_g, const double* __restrict__ Xmu_g,
                   const double* __restrict__ d2_g, const double* __restrict__ g0_g,
                   double* __restrict__ p2_part, double* __restrict__ dz_part, double* __restrict__ dlam_part,
@@ -1386,8 +1386,8 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
   double* p2acc = lds;                                    // [tri]
   double* dzacc = lds + tri;                              // [QP x 128]
   double* hbuf = dzacc + QP * RGP_PSI2_TEAM;              // [NT x 128]
-  double* rowd = hbuf + PSI2_MAX_NT * RGP_PSI2_TEAM;      // [NT x RD]
-  double* red = rowd + PSI2_MAX_NT * RD;                  // [8 waves x RED_WAVE]
+  double* rowd = hbuf + NT * RGP_PSI2_TEAM;               // [NT x RD]
+  double* red = rowd + NT * RD;                           // [8 waves x RED_WAVE]
   double* res = red + 8 * RED_WAVE;                       // [8 waves x 2 x RW]
   double* etab = res + 8 * 2 * RW;                        // [256] 2^(j/256)
 #ifdef PSI2_STAMPS
@@ -1396,17 +1396,19 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
 
   const int t = threadIdx.x;
   const int wave = t >> 6, lane = t & 63;
-  const int team_raw = t / M;
-  const bool act = team_raw < NT;                         // the last 512 - NT*M threads idle
-  const int team = act ? team_raw : NT - 1;
-  const int tr = act ? t - team_raw * M : M - 1;
+  // team stride TS = max(M, 64): teams of exactly M threads for M >= 64, one (partly idle) wave per team below that
+  const int team_raw = t / TS;
+  const int tr_raw = t - team_raw * TS;
+  const bool act = team_raw < NT && tr_raw < M;           // idle: the last 512 - NT*TS threads and the lanes >= M of a team
+  const int team = team_raw < NT ? team_raw : NT - 1;
+  const int tr = act ? tr_raw : M - 1;
   const double* __restrict__ zrowp = Zc + (size_t)tr * QP;
 #define zrow(q) zrowp[q]
   double* hb = hbuf + team * RGP_PSI2_TEAM;
   const double* rd = rowd + team * RD;
   // team boundary inside this wave: lanes < bnd belong to team ta, the others to ta + 1
-  const int ta = (64 * wave) / M;
-  const int bnd = __builtin_amdgcn_readfirstlane(((ta + 1) * M - 64 * wave < 64) ? (ta + 1) * M - 64 * wave : 64);
+  const int ta = (64 * wave) / TS;
+  const int bnd = __builtin_amdgcn_readfirstlane(((ta + 1) * TS - 64 * wave < 64) ? (ta + 1) * TS - 64 * wave : 64);
   const bool inA = lane < bnd;
 
   for (int i = t; i < tri; i += PSI2_T4) p2acc[i] = 0.0;
@@ -1424,11 +1426,10 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
   const double* __restrict__ dlrow = dLs_g + tr;
   const int tr_own = act ? tr : 0x7fffffff;          // inactive threads own no slot
 
-  // staged row element of this thread (one per thread: NT*RD <= 512): loaded one iteration ahead
-  const int sk = t / RD, sj = t - sk * RD;
-  const bool stager = t < NT * RD;
-  auto stage_load = [&](int64_t rr) -> double {
-    if (!stager) return 0.0;
+  // staged row elements of this thread (NT*RD <= 1024: at most two per thread), loaded one iteration ahead
+  const bool stager = t < NT * RD, stager2 = t + PSI2_T4 < NT * RD;
+  auto stage_load = [&](int64_t rr, int e) -> double {
+    const int sk = e / RD, sj = e - sk * RD;
     const int64_t nk = (rr + sk < r1) ? rr + sk : r1 - 1;
     if (nk < 0) return 0.0;
     if (sj < QP) return d2_g[nk * QP + sj];
@@ -1436,8 +1437,10 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     if (sj == 2 * QP) return g0_g[nk];
     return 0.0;
   };
-  double staged = (r0 < r1) ? stage_load(r0) : 0.0;
+  double staged = (stager && r0 < r1) ? stage_load(r0, t) : 0.0;
+  double staged2 = (stager2 && r0 < r1) ? stage_load(r0, t + PSI2_T4) : 0.0;
   if (stager) rowd[t] = staged;
+  if (stager2) rowd[t + PSI2_T4] = staged2;
   __syncthreads();
 
   for (int64_t rr = r0; rr < r1; rr += NT) {
@@ -1449,12 +1452,13 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     const bool valid = rr + team < r1;
     const int64_t n = valid ? rr + team : r1 - 1;
     // loads whose latency hides under the sweep: next iteration's rows, and this row's gradient slots
-    staged = (rr + NT < r1) ? stage_load(rr + NT) : 0.0;
-    const bool grad_thread = act && tr < QP && valid;
+    staged = (stager && rr + NT < r1) ? stage_load(rr + NT, t) : 0.0;
+    staged2 = (stager2 && rr + NT < r1) ? stage_load(rr + NT, t + PSI2_T4) : 0.0;
+    const bool grad_thread = team_raw < NT && tr_raw < QP && valid;      // lanes >= M of a short team do this job too (TS >= 64 >= QP)
     double g_old_mu = 0.0, g_old_S = 0.0;
-    if (grad_thread && accumulate && tr < Q) {
-      g_old_mu = gmu_g[n * QP + tr];
-      g_old_S = gS_g[n * QP + tr];
+    if (grad_thread && accumulate && tr_raw < Q) {
+      g_old_mu = gmu_g[n * QP + tr_raw];
+      g_old_S = gS_g[n * QP + tr_raw];
     }
     STAMP(tA);
     double dzl[QP];
@@ -1559,12 +1563,12 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     STAMP(tE);
     // row gradients: thread (team, q) combines the wave partials that cover its team, in wave order
     if (grad_thread) {
-      const int q = tr;
+      const int q = tr_raw;
       if (q < Q) {
-        const int w0 = (team * M) >> 6, w1 = (team * M + M - 1) >> 6;
+        const int w0 = (team * TS) >> 6, w1 = (team * TS + M - 1) >> 6;
         double w = 0.0, a1 = 0.0, a23 = 0.0;
         for (int wv = w0; wv <= w1; ++wv) {
-          const int slot = ((64 * wv) / M == team) ? 0 : 1;
+          const int slot = ((64 * wv) / TS == team) ? 0 : 1;
           const double* tres = res + ((size_t)wv * 2 + slot) * RW;
           w += tres[2 * QP];
           a1 += tres[q];
@@ -1586,6 +1590,7 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     }
     __syncthreads();                                  // everyone is done with rowd / res / hbuf of this iteration
     if (stager) rowd[t] = staged;
+    if (stager2) rowd[t + PSI2_T4] = staged2;
     __syncthreads();
     STAMP(tF);
   }
@@ -1599,23 +1604,27 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     double* outz = dz_part + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM;
     for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) outz[i] = dzacc[i];
   }
-  if (act && tr < QP) dlam_part[((size_t)blockIdx.x * NT + team) * QP + tr] = (tr < Q) ? dlam_acc : 0.0;
-  if (act && tr == 0) wsum_part[(size_t)blockIdx.x * NT + team] = wsum_acc;
+  if (team_raw < NT && tr_raw < QP) dlam_part[((size_t)blockIdx.x * NT + team) * QP + tr_raw] = (tr_raw < Q) ? dlam_acc : 0.0;
+  if (team_raw < NT && tr_raw == 0) wsum_part[(size_t)blockIdx.x * NT + team] = wsum_acc;
 }
 #undef zrow
 
-static size_t psi2_rowsN_lds(int M, int QP) {
+static int psi2_team_stride(int M) { return M < 64 ? 64 : M; }
+
+static size_t psi2_rowsN_lds(int M, int QP, int NT) {
   const size_t tri = (size_t)M * (M + 1) / 2;
-  return (tri + (size_t)QP * RGP_PSI2_TEAM + PSI2_MAX_NT * RGP_PSI2_TEAM + PSI2_MAX_NT * (2 * (size_t)QP + 2) +
+  return (tri + (size_t)QP * RGP_PSI2_TEAM + (size_t)NT * RGP_PSI2_TEAM + (size_t)NT * (2 * (size_t)QP + 2) +
           8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8) + PSI2_EXP_TAB) * sizeof(double);
 }
 
 // number of packed teams (0: use the four-team / two-team kernels)
 int psi2_packed_teams(int M, int QP) {
   static const bool off = getenv("RGP_PSI2_NO_PACKED") != nullptr;
-  if (off || M < 64 || M > 102) return 0;
-  if (psi2_rowsN_lds(M, QP) > 160 * 1024) return 0;
-  return PSI2_T4 / M;
+  if (off || M < 1 || M > RGP_MAX_M) return 0;
+  const int nt = PSI2_T4 / psi2_team_stride(M);
+  if (nt > PSI2_MAX_NT || (size_t)nt * (2 * (size_t)QP + 2) > 2 * PSI2_T4) return 0;
+  if (psi2_rowsN_lds(M, QP, nt) > 160 * 1024) return 0;
+  return nt;
 }
 
 // LDS bytes of the four-team kernel
@@ -1633,7 +1642,7 @@ bool psi2_use_rows4(int M, int QP) {
 Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   Psi2Plan pl;
   const int nt = (fwd && bwd && !h->deterministic) ? psi2_packed_teams(M, QP) : 0;
-  if (nt > 4) {
+  if (nt >= 4) {
     int64_t g = h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0);     // one 512-thread workgroup per CU, nt rows in flight;
                                                                           // one CU stays free for the side-stream M x M chains
     if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
@@ -1675,13 +1684,13 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
                        a.o.gmu, a.o.gS, a.o.accumulate);                                                              \
   } while (0)
   const int nt = (fwd && bwd && packed_ok) ? psi2_packed_teams(a.M, QP) : 0;
-  if (nt > 4) {
-    const size_t ln = psi2_rowsN_lds(a.M, QP);
+  if (nt >= 4) {
+    const size_t ln = psi2_rowsN_lds(a.M, QP, nt);
     static double* dbgbuf = nullptr;
     if (!dbgbuf && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf, 256 * 9 * sizeof(double));
     hipError_t e = hipFuncSetAttribute((const void*)psi2_rowsN_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((psi2_rowsN_kernel<QP>), dim3(nblk), dim3(PSI2_T4), ln, s, a.N, a.M, a.Q, nt, a.Zc, a.lam, a.dLs, a.Xmu,
+    hipLaunchKernelGGL((psi2_rowsN_kernel<QP>), dim3(nblk), dim3(PSI2_T4), ln, s, a.N, a.M, a.Q, nt, psi2_team_stride(a.M), a.Zc, a.lam, a.dLs, a.Xmu,
                        a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
                        a.o.accumulate, dbgbuf);
     if (dbgbuf) {
