@@ -1545,11 +1545,11 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     __syncthreads();
     STAMP(tG);
 #endif
-    // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab: one team after the other (fixed order), each as one
-    // batch of loads, adds and stores
+    // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab
 #pragma unroll
     for (int q = 0; q < QP; ++q) y[q] = rd[q] * (v * (2.0 * rd[QP + q] - zrow(q)) - y[q]);
     STAMP(tH);
+#ifdef PSI2_DZ_PHASES
     for (int k = 0; k < NT; ++k) {
       if (act && team_raw == k) {
         double tmp[QP];
@@ -1560,6 +1560,15 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
       }
       __syncthreads();
     }
+#else
+    // all teams at once with LDS fp64 atomics (hardware order, like the forward sums; the deterministic mode uses the
+    // rotating-team kernel): one barrier instead of NT, which also publishes the wave partials to the row-gradient threads
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < QP; ++q) atomicAdd(&dzacc[q * RGP_PSI2_TEAM + tr], y[q]);
+    }
+    __syncthreads();
+#endif
     STAMP(tE);
     // row gradients: thread (team, q) combines the wave partials that cover its team, in wave order
     if (grad_thread) {
