@@ -1484,18 +1484,23 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     for (int q = 0; q < QP; ++q) y[q] = 0.0;
     {
       const int last = M - 1;
-      double dlA = dlrow[0];
-      double dlB = dlrow[(size_t)((1 < M) ? 1 : last) * M];
-      for (int mp = 0; mp < M; mp += 2) {
-        const int mpa = mp, mpb = (mp + 1 < M) ? mp + 1 : last;
-        const double dla = dlA, dlb = dlB;
-        dlA = dlrow[(size_t)((mp + 2 < M) ? mp + 2 : last) * M];
-        dlB = dlrow[(size_t)((mp + 3 < M) ? mp + 3 : last) * M];
-        psi2_pair_fix<QP>(Zc + (size_t)mpa * QP, dzl, y, v, base, hb[mpa], dla, p2acc + (mpa * (mpa + 1) / 2 + tr),
-                          mpa >= tr_own, etab);
-        if (mp + 1 < M)
-          psi2_pair_fix<QP>(Zc + (size_t)mpb * QP, dzl, y, v, base, hb[mpb], dlb, p2acc + (mpb * (mpb + 1) / 2 + tr),
-                            mpb >= tr_own, etab);
+      double dlv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
+      for (int mp = 0; mp < M; mp += 4) {
+        double dlc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dlc[u] = dlv[u];
+          dlv[u] = dlrow[(size_t)((mp + 4 + u < M) ? mp + 4 + u : last) * M];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mq = mp + u;
+          if (u == 0 || mq < M)
+            psi2_pair_fix<QP>(Zc + (size_t)mq * QP, dzl, y, v, base, hb[mq], dlc[u], p2acc + (mq * (mq + 1) / 2 + tr),
+                              mq >= tr_own, etab);
+        }
       }
     }
 
