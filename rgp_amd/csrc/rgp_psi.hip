@@ -1344,6 +1344,9 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
 //   * the per-row reductions over m split each wave's transposed sum at the team boundary.
 // ------------------------------------------------------------------------------------------------------------------
 #define PSI2_MAX_NT 8
+#ifndef PSI2_UNR
+#define PSI2_UNR 4            // pairs per trip of the sweep loop
+#endif
 
 template <int QP>
 static __device__ __forceinline__ void psi2_pair_fix(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP],
@@ -1484,18 +1487,18 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     for (int q = 0; q < QP; ++q) y[q] = 0.0;
     {
       const int last = M - 1;
-      double dlv[4];
+      double dlv[PSI2_UNR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
-      for (int mp = 0; mp < M; mp += 4) {
-        double dlc[4];
+      for (int u = 0; u < PSI2_UNR; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
+      for (int mp = 0; mp < M; mp += PSI2_UNR) {
+        double dlc[PSI2_UNR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PSI2_UNR; ++u) {
           dlc[u] = dlv[u];
-          dlv[u] = dlrow[(size_t)((mp + 4 + u < M) ? mp + 4 + u : last) * M];
+          dlv[u] = dlrow[(size_t)((mp + PSI2_UNR + u < M) ? mp + PSI2_UNR + u : last) * M];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PSI2_UNR; ++u) {
           const int mq = mp + u;
           if (u == 0 || mq < M)
             psi2_pair_fix<QP>(Zc + (size_t)mq * QP, dzl, y, v, base, hb[mq], dlc[u], p2acc + (mq * (mq + 1) / 2 + tr),
