@@ -1774,7 +1774,15 @@ __global__ void __launch_bounds__(256) reduce_kernel(int nblk, int64_t len, int6
   const int64_t i = (int64_t)blockIdx.x * 32 + e;
   double s = 0.0;
   if (i < len) {
-    for (int b = g; b < nblk; b += 8) s += part[(size_t)b * stride + i];
+    int b = g;
+    for (; b + 56 < nblk; b += 64) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = part[(size_t)(b + 8 * u) * stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; b < nblk; b += 8) s += part[(size_t)b * stride + i];
   }
   sm[g][e] = s;
   __syncthreads();
@@ -1806,7 +1814,16 @@ __global__ void __launch_bounds__(256) reduce_batch_kernel(ReduceBatch rb) {
   const int64_t i = (int64_t)(blockIdx.x - rb.blk_off[k]) * 32 + e;
   double s = 0.0;
   if (i < sg.len) {
-    for (int b = g; b < sg.nblk; b += 8) s += sg.part[(size_t)b * sg.stride + i];
+    // same summation order as a plain loop; the loads of eight partials are in flight together
+    int b = g;
+    for (; b + 56 < sg.nblk; b += 64) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = sg.part[(size_t)(b + 8 * u) * sg.stride + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += x[u];
+    }
+    for (; b < sg.nblk; b += 8) s += sg.part[(size_t)b * sg.stride + i];
   }
   sm[g][e] = s;
   __syncthreads();
