@@ -96,8 +96,10 @@ def main():
     n_mb = n_loc // mb_loc
     def step(k):
         j = k % n_mb
+        # lazy_elbo: the ELBO scalar is produced on the library's side stream; it is read only after the final synchronisation
         return m.svi_step(slice(j * mb_loc, (j + 1) * mb_loc), lr=a.lr, allreduce=allreduce,
-                          qU_ratio=float(mb) / n_total / world if world > 1 else None, update=not a.no_update)
+                          qU_ratio=float(mb) / n_total / world if world > 1 else None, update=not a.no_update,
+                          lazy_elbo=not a.no_update)
 
     for k in range(a.warmup):
         step(k)

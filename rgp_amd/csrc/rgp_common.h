@@ -80,6 +80,8 @@ struct rgp_ctx {
   hipEvent_t ev_pre_a[NSLOT] = {};   // K_uu factor + Cpsi1 ready (psi1 passes)
   hipEvent_t ev_pre_b[NSLOT] = {};   // dL_dpsi2 ready (psi2 pass)
   hipEvent_t ev_rows[NSLOT] = {};    // window tables + row terms ready (side_rows stream)
+  hipEvent_t ev_prepz[NSLOT] = {};   // Z-derived terms of the slot written (chain-only prepare, side_pre stream)
+  bool prepz_recorded[NSLOT] = {};
   hipEvent_t ev_yry[NSLOT] = {};     // sum of squared outputs reduced (needed by the chain's last stage only)
   hipEvent_t ev_main = nullptr;                                          // main-stream position at prepare time
   hipEvent_t ev_done[NSLOT] = {};

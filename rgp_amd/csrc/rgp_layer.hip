@@ -80,6 +80,7 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
     hipEventCreateWithFlags(&h->ev_pre_a[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_rows[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_yry[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_prepz[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_pre_b[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_slot_main[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming);
@@ -953,8 +954,10 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
     h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
     if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
   }
-  hipStream_t s = h->overlap ? h->side_rows : h->stream;      // everything below is off the main stream
-  hipStream_t s_pre = h->overlap ? h->side_pre : s;
+  hipStream_t s_pre = h->overlap ? h->side_pre : h->stream;
+  // everything below is off the main stream: row work on side_rows; a chain-only prepare keeps off that stream too, because
+  // it waits for the side_post stream and would hold back the next step's row work queued behind it
+  hipStream_t s = h->overlap ? (mode == 1 ? h->side_pre : h->side_rows) : h->stream;
   if (h->overlap) {
     if (mode == 1) {
       // the parameters were updated on the side_post stream (rgp_adam_step_post); the slot's previous users are covered
@@ -974,8 +977,12 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
     // the side-stream work that last used this slot must be finished before it is overwritten
     if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[slot], 0));
     launch_prep_z(s, M, Q, L.zt.QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+    if (h->overlap && mode == 1) {                  // the rows-only prepare (side_rows stream) reads c and lam
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_prepz[slot], s));
+      h->prepz_recorded[slot] = true;
+    }
     c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
-    if (h->overlap) {
+    if (h->overlap && s != s_pre) {
       RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
       RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
     }
@@ -983,6 +990,7 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
     if (h->overlap) RGP_HIP_CHECK(h, hipEventRecord(h->ev_pre[slot], s_pre));
   }
   if (mode != 1) {
+    if (h->overlap && mode == 2 && h->prepz_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_prepz[slot], 0));
     // tables + rows
     hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
                        in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,

@@ -518,16 +518,20 @@ class DeepAutoreg(object):
         self._adam = dict(m=torch.zeros_like(self.param_array), v=torch.zeros_like(self.param_array),
                           t_glob=0, t_loc=np.zeros(self.nSeq, dtype=np.int64))
 
-    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True):
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True, lazy_elbo=False):
         """One SVI step on the sequences ``seqs`` (slice of contiguous indices or index list): ELBO + gradients,
         optional all-reduce of the global bucket (data-parallel), one Adam update of the global parameters and of the
-        touched sequences' latent parameters.  Returns the device ELBO scalar (pre-update)."""
+        touched sequences' latent parameters.  Returns the device ELBO scalar (pre-update).
+
+        lazy_elbo=True (pipelined steps only): the ELBO is summed on the library's side stream and the main stream does not
+        wait for the last layer's M x M algebra, so the next step's row work starts earlier; the returned tensor may only be
+        read after ``handle.join()`` / a device synchronisation."""
         if self._adam is None:
             self._init_adam()
         ad, h = self._adam, self.handle
         pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate
         if pipelined:
-            elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio)
+            elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo)
         else:
             elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
             if allreduce is not None:
@@ -555,7 +559,7 @@ class DeepAutoreg(object):
                             self.positive[sl], lr, t)
         return elbo
 
-    def _svi_step_pipelined(self, seqs, lr, allreduce, qU_ratio):
+    def _svi_step_pipelined(self, seqs, lr, allreduce, qU_ratio, lazy_elbo=False):
         """ELBO + gradients + update of the GLOBAL parameters, layer by layer: as soon as a layer's gradients exist (library
         side stream) they are all-reduced and applied there, and the M x M chain of the NEXT step is started for that layer
         while the main stream is still busy with the psi passes of the layers below (include/rgp_hip.h, pipelining
@@ -569,7 +573,7 @@ class DeepAutoreg(object):
         for lin, _ in ios:
             h.layer_prepare(lin, PREPARE_ROWS_ONLY if self._chain_ready else 0)
         ad['t_glob'] += 1
-        if allreduce is not None and self._post_stream is None:
+        if (allreduce is not None or lazy_elbo) and self._post_stream is None:
             self._post_stream = torch.cuda.ExternalStream(h.get_stream(1), device=self.device)
         for (lin, lout), L in zip(ios, self.layers):
             h.layer_step(lin, lout)
@@ -583,12 +587,21 @@ class DeepAutoreg(object):
             h.layer_prepare(lin, PREPARE_CHAIN_ONLY)
         self._chain_ready = True
         self._chain_n = [lin.N for lin, _ in ios]
+        self._last_n_batch = n_batch
+        if lazy_elbo:
+            # the per-layer ELBO terms are written on the side stream; summing them there keeps the main stream free of the
+            # last layer's M x M algebra (the latent gradients it needs next come from main-stream kernels)
+            with torch.cuda.stream(self._post_stream):
+                elbo = self._elbo_buf.sum()
+                if allreduce is not None:
+                    allreduce(elbo)
+                self.grad_array[self.elbo_slot] = elbo
+            return elbo
         h.join()
         elbo = self._elbo_buf.sum()
         if allreduce is not None:
             allreduce(elbo)
         self.grad_array[self.elbo_slot] = elbo
-        self._last_n_batch = n_batch
         return elbo
 
     # ------------------------------------------------------------------------------------------------------------
