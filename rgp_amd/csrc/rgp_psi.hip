@@ -661,13 +661,16 @@ psi1_svi_fwd2_kernel(const int64_t N, const int M, const int D, const double* __
 // pass Z.  Lane = two inducing rows (m, m + 64), wave = one quarter of the q columns; all four waves walk all rows of the
 // tile.  One broadcast ds_read_b128 of (e, e*mu)[row, q] then feeds four multiply-adds instead of two, and a (m, q) slot has
 // exactly one owner, so nothing is combined at the end.  The Lp tile is staged in LDS (coalesced 128-column rows).
+#ifndef P1Z_TILE
+#define P1Z_TILE 16                // rows per tile of pass Z: 26 KB of LDS per workgroup at QP = 40, six workgroups per CU
+#endif
 template <int QP>
 __global__ void __launch_bounds__(256)
 psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
                    const double* __restrict__ em, const double* __restrict__ Lp, double* __restrict__ dz_part) {
   constexpr int QW = QP / 4;                               // QP is a multiple of 8
-  __shared__ __attribute__((aligned(16))) double buf[2 * P1_TILE * QP];
-  __shared__ double lps[P1_TILE * RGP_PSI2_TEAM];
+  __shared__ __attribute__((aligned(16))) double buf[2 * P1Z_TILE * QP];
+  __shared__ double lps[P1Z_TILE * RGP_PSI2_TEAM];
   double2* ee = reinterpret_cast<double2*>(buf);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -682,22 +685,22 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
     a0[j] = 0.0;
     a1[j] = 0.0;
   }
-  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1Z_TILE - 1) / P1Z_TILE * P1Z_TILE;
   const int64_t r0 = (int64_t)blockIdx.x * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
-  for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
-    const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
+  for (int64_t rb = r0; rb < r1; rb += P1Z_TILE) {
+    const int nr = (int)((r1 - rb) < P1Z_TILE ? (r1 - rb) : P1Z_TILE);
     {
       const int64_t lim = (int64_t)nr * QP - 1;
       double2 v[QP / 8];
-      double lv[P1_TILE * RGP_PSI2_TEAM / 256];
+      double lv[P1Z_TILE * RGP_PSI2_TEAM / 256];
 #pragma unroll
       for (int k = 0; k < QP / 8; ++k) {
         const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
         v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
       }
 #pragma unroll
-      for (int k = 0; k < P1_TILE * RGP_PSI2_TEAM / 256; ++k) {
+      for (int k = 0; k < P1Z_TILE * RGP_PSI2_TEAM / 256; ++k) {
         const int i = t + 256 * k, row = i >> 7, col = i & 127;
         const bool ok = row < nr && col < M;
         const double x = Lp[(rb + (ok ? row : 0)) * M + (ok ? col : 0)];
@@ -707,7 +710,7 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
 #pragma unroll
       for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
 #pragma unroll
-      for (int k = 0; k < P1_TILE * RGP_PSI2_TEAM / 256; ++k) lps[t + 256 * k] = lv[k];
+      for (int k = 0; k < P1Z_TILE * RGP_PSI2_TEAM / 256; ++k) lps[t + 256 * k] = lv[k];
     }
     __syncthreads();
 #pragma unroll 2
