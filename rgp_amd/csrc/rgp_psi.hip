@@ -692,10 +692,11 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
     const int nr = (int)((r1 - rb) < P1Z_TILE ? (r1 - rb) : P1Z_TILE);
     {
       const int64_t lim = (int64_t)nr * QP - 1;
-      double2 v[QP / 8];
+      constexpr int NE = (P1Z_TILE * QP + 255) / 256;          // (e, e*mu) entries per thread
+      double2 v[NE];
       double lv[P1Z_TILE * RGP_PSI2_TEAM / 256];
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) {
+      for (int k = 0; k < NE; ++k) {
         const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
         v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
       }
@@ -708,7 +709,8 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+      for (int k = 0; k < NE; ++k)
+        if (t + 256 * k < P1Z_TILE * QP) ee[t + 256 * k] = v[k];
 #pragma unroll
       for (int k = 0; k < P1Z_TILE * RGP_PSI2_TEAM / 256; ++k) lps[t + 256 * k] = lv[k];
     }
