@@ -107,6 +107,161 @@ static __device__ void lds_trtri(double* L, int M, int ld) {
   __syncthreads();
 }
 
+// ---- blocked factorisations: 16 x 16 diagonal blocks in registers of one wave, panels and trailing updates on all waves ----
+// The column-by-column versions above spend ~1 us per column (dependent LDS round trips); with the diagonal block held one row
+// per lane and exchanged with v_readlane a block costs ~3 us, and the O(M^3) part runs on 1024 threads.
+#define FB 16
+#define CH_MAX_M 128
+#define LDS_FACT_EXTRA (CH_MAX_M * FB + 2 * FB)        // doubles of LDS behind the matrix: panel buffer + 1/diag
+
+// Cholesky of the nb x nb block at A (lower, in place), wave 0 only; writes 1/diag to rdiag[0..nb).
+static __device__ void chol16_wave(double* A, int ld, int nb, int* status, int piv_off, double* rdiag) {
+  const int lane = threadIdx.x & 63, i = lane & 15;
+  double a[FB];
+#pragma unroll
+  for (int c = 0; c < FB; ++c) a[c] = (i < nb && c <= i) ? A[i * ld + c] : ((i == c) ? 1.0 : 0.0);     // identity padding
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    const double piv = readlane_f64(a[j], j);
+    if (j < nb && !(piv > 0.0) && lane == 0) {
+      if (atomicCAS(&status[0], 0, RGP_ERR_NOT_PD) == 0) status[1] = piv_off + j;
+    }
+    const double d = sqrt(piv), rd = 1.0 / d;
+    if (lane == 0 && j < nb) rdiag[j] = rd;
+    if (i == j) a[j] = d;
+    else if (i > j) a[j] *= rd;
+#pragma unroll
+    for (int c = j + 1; c < FB; ++c) {
+      const double lcj = readlane_f64(a[j], c);          // L[c][j]
+      if (i >= c) a[c] -= a[j] * lcj;
+    }
+  }
+  if (lane < FB && i < nb) {
+#pragma unroll
+    for (int c = 0; c < FB; ++c)
+      if (c < nb) A[i * ld + c] = (c <= i) ? a[c] : 0.0;
+  }
+}
+
+// Inverse of the nb x nb lower-triangular block at L (in place), wave 0 only: lane c solves L x = e_c.
+static __device__ void trtri16_wave(double* L, int ld, int nb) {
+  const int lane = threadIdx.x & 63, i = lane & 15;
+  double a[FB], x[FB];
+#pragma unroll
+  for (int c = 0; c < FB; ++c) a[c] = (i < nb && c <= i && c < nb) ? L[i * ld + c] : ((i == c) ? 1.0 : 0.0);
+  double dsel = 1.0;                                        // this lane's diagonal element
+#pragma unroll
+  for (int c = 0; c < FB; ++c) dsel = (i == c) ? a[c] : dsel;
+  const double rdv = 1.0 / dsel;
+#pragma unroll
+  for (int r = 0; r < FB; ++r) {
+    double sacc = (r == i) ? 1.0 : 0.0;                    // lane i holds column i of the inverse
+#pragma unroll
+    for (int k = 0; k < r; ++k) sacc -= readlane_f64(a[k], r) * x[k];         // L[r][k] x[k]
+    x[r] = sacc * readlane_f64(rdv, r);
+  }
+  if (lane < FB && i < nb) {
+#pragma unroll
+    for (int r = 0; r < FB; ++r)
+      if (r < nb && r >= i) L[r * ld + i] = x[r];
+  }
+}
+
+// blocked right-looking Cholesky, lower, in place.  `ext` = LDS_FACT_EXTRA doubles of LDS behind the matrix.
+static __device__ void lds_chol_blocked(double* A, int M, int ld, int* status, double* ext) {
+  double* rdiag = ext + (size_t)CH_MAX_M * FB;
+  const int t = threadIdx.x, T = blockDim.x;
+  for (int kb = 0; kb < M; kb += FB) {
+    const int nb = (M - kb < FB) ? (M - kb) : FB;
+    if (t < 64) chol16_wave(A + kb * ld + kb, ld, nb, status, kb, rdiag);
+    __syncthreads();
+    const int r0 = kb + nb, nrem = M - r0;
+    if (nrem > 0) {
+      if (t < nrem) {                                        // panel: X L11^T = A21, one row per thread
+        const int row = r0 + t;
+        double x[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+          if (j < nb) {
+            double sacc = A[row * ld + kb + j];
+#pragma unroll
+            for (int c = 0; c < j; ++c) sacc -= x[c] * A[(kb + j) * ld + kb + c];
+            x[j] = sacc * rdiag[j];
+          } else {
+            x[j] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+          if (j < nb) A[row * ld + kb + j] = x[j];
+      }
+      __syncthreads();
+      for (int e = t; e < nrem * nrem; e += T) {            // trailing update of the lower triangle
+        const int i = e / nrem, c = e - i * nrem;
+        if (c <= i) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            if (j < nb) sacc += A[(r0 + i) * ld + kb + j] * A[(r0 + c) * ld + kb + j];
+          A[(r0 + i) * ld + r0 + c] -= sacc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = t; e < M * M; e += T) {
+    const int i = e / M, c = e - i * M;
+    if (c > i) A[i * ld + c] = 0.0;
+  }
+  __syncthreads();
+}
+
+// blocked in-place inverse of a lower-triangular matrix (LAPACK dtrtri order: block columns last to first).
+static __device__ void lds_trtri_blocked(double* L, int M, int ld, double* ext) {
+  double* tmp = ext;                                        // [nrem x FB]
+  double* rdiag = ext + (size_t)CH_MAX_M * FB;
+  const int t = threadIdx.x, T = blockDim.x;
+  const int nblk = (M + FB - 1) / FB;
+  for (int jb = (nblk - 1) * FB; jb >= 0; jb -= FB) {
+    const int nb = (M - jb < FB) ? (M - jb) : FB;
+    const int r0 = jb + nb, nrem = M - r0;
+    if (nrem > 0) {
+      if (t < nb) rdiag[t] = 1.0 / L[(jb + t) * ld + jb + t];
+      // tmp = Linv22 * L21   (Linv22: the already inverted trailing triangle)
+      for (int e = t; e < nrem * FB; e += T) {
+        const int i = e / FB, c = e - i * FB;
+        double sacc = 0.0;
+        if (c < nb)
+          for (int k = 0; k <= i; ++k) sacc += L[(r0 + i) * ld + r0 + k] * L[(r0 + k) * ld + jb + c];
+        tmp[e] = sacc;
+      }
+      __syncthreads();
+      if (t < nrem) {                                        // X L11 = -tmp, one row per thread, columns last to first
+        double x[FB];
+#pragma unroll
+        for (int cc = 0; cc < FB; ++cc) {
+          const int c = FB - 1 - cc;
+          if (c < nb) {
+            double sacc = -tmp[t * FB + c];
+#pragma unroll
+            for (int k = c + 1; k < FB; ++k)
+              if (k < nb) sacc -= x[k] * L[(jb + k) * ld + jb + c];
+            x[c] = sacc * rdiag[c];
+          } else {
+            x[c] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < FB; ++c)
+          if (c < nb) L[(r0 + t) * ld + jb + c] = x[c];
+      }
+      __syncthreads();
+    }
+    if (t < 64) trtri16_wave(L + jb * ld + jb, ld, nb);
+    __syncthreads();
+  }
+}
+
 static __device__ void copy_in(double* lds, int ld, const double* g, int M) {
   for (int i = threadIdx.x; i < M * M; i += blockDim.x) lds[(i / M) * ld + (i % M)] = g[i];
   __syncthreads();
@@ -218,9 +373,9 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_a_kernel(SviChain c)
   const double beta = 1.0 / c.noise[0];                        // svi_vardtc.py:80
   // Lm = chol(K), Linv
   copy_in(lds, ld, c.Kj, M);
-  lds_chol(lds, M, ld, c.status);
+  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);
   double ldm = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
-  lds_trtri(lds, M, ld);
+  lds_trtri_blocked(lds, M, ld, lds + (size_t)M * ld);
   copy_out(c.Linv, lds, ld, M);
   // gmu = Linv mu ; Kinv_mu = Linv^T gmu                          (svi_vardtc.py:97,153)
   wg_gemm<false, false>(M, D, M, 1.0, c.Linv, M, c.qU_m, D, 0.0, c.gmu, D, lds);
@@ -242,7 +397,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c)
   if (t < M) c.S[t * M + t] += c.qU_a[0];
   __syncthreads();
   copy_in(lds, ld, c.S, M);
-  lds_chol(lds, M, ld, c.status);
+  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);
   double lds_ = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
   copy_out(c.Ls, lds, ld, M);
   // E = Linv Ls                                                   (svi_vardtc.py:96)
@@ -267,7 +422,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_c_kernel(SviChain c)
   const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
   const double Dd = (double)D;
   copy_in(lds, ld, c.Ls, M);
-  lds_trtri(lds, M, ld);
+  lds_trtri_blocked(lds, M, ld, lds + (size_t)M * ld);
   copy_out(c.LsInv, lds, ld, M);
   wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
   wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.Sinv, M, lds);
@@ -372,7 +527,7 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
 
 rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream, hipEvent_t ev_after_a, hipEvent_t ev_after_b) {
   if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
-  size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  size_t lds = ((size_t)c.M * (c.M + 1) + LDS_FACT_EXTRA) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)svi_chain_pre_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -410,8 +565,8 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   const double Dd = (double)D, Nd = (double)c.N;
   const double beta = 1.0 / fmax(c.noise[0], 1e-6);                 // vardtc.py:102
   copy_in(lds, ld, c.Kj, M);
-  lds_chol(lds, M, ld, c.status);
-  lds_trtri(lds, M, ld);
+  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);
+  lds_trtri_blocked(lds, M, ld, lds + (size_t)M * ld);
   copy_out(c.Linv, lds, ld, M);
   // A = beta Linv psi2 Linv^T ; Lambda = I + A ; LL = chol(Lambda)          (:120-125)
   wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M, lds);
@@ -419,9 +574,9 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.A[i] + ((i / M == i % M) ? 1.0 : 0.0);
   __syncthreads();
   copy_in(lds, ld, c.T1, M);
-  lds_chol(lds, M, ld, c.status);
+  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);
   const double ldLL = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
-  lds_trtri(lds, M, ld);
+  lds_trtri_blocked(lds, M, ld, lds + (size_t)M * ld);
   copy_out(c.LLinv, lds, ld, M);
   wg_gemm<false, false>(M, M, M, 1.0, c.LLinv, M, c.Linv, M, 0.0, c.Li, M, lds);          // Li = L^-1
   wg_gemm<true, false>(M, M, M, 1.0, c.Li, M, c.Li, M, 0.0, c.G2, M, lds);                // G2 = Li^T Li
@@ -482,7 +637,7 @@ void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws) {
 
 rgp_status launch_vardtc_chain(rgp_handle h, const VarDtcChain& c) {
   if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "vardtc chain: M > 128 needs the blocked factorisation (not in this build)");
-  size_t lds = (size_t)c.M * (c.M + 1) * sizeof(double);
+  size_t lds = ((size_t)c.M * (c.M + 1) + LDS_FACT_EXTRA) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)vardtc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("vardtc chain LDS attr: ") + hipGetErrorString(e));
