@@ -1708,13 +1708,18 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
   const int nt = (fwd && bwd && packed_ok) ? psi2_packed_teams(a.M, QP) : 0;
   if (nt >= 4) {
     const size_t ln = psi2_rowsN_lds(a.M, QP, nt);
-    static double* dbgbuf = nullptr;
-    if (!dbgbuf && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf, 256 * 9 * sizeof(double));
+    double* dbgbuf = nullptr;
+#ifdef PSI2_STAMPS                                   // per-stage cycle stamps (profiling builds: make CXXFLAGS+=-DPSI2_STAMPS, RGP_STAMPS=1)
+    static double* dbgbuf_s = nullptr;
+    if (!dbgbuf_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf_s, 256 * 9 * sizeof(double));
+    dbgbuf = dbgbuf_s;
+#endif
     hipError_t e = hipFuncSetAttribute((const void*)psi2_rowsN_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((psi2_rowsN_kernel<QP>), dim3(nblk), dim3(PSI2_T4), ln, s, a.N, a.M, a.Q, nt, psi2_team_stride(a.M), a.Zc, a.lam, a.dLs, a.Xmu,
                        a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu, a.o.gS,
                        a.o.accumulate, dbgbuf);
+#ifdef PSI2_STAMPS
     if (dbgbuf) {
       (void)hipStreamSynchronize(s);
       static double hb[256 * 9];
@@ -1722,9 +1727,10 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
       double a[7] = {0};
       for (int b = 0; b < nblk; ++b) for (int k = 0; k < 7; ++k) a[k] += hb[b * 8 + k] / nblk;
       double th = 0; for (int b = 0; b < nblk; ++b) th += hb[256 * 8 + b] / nblk;
-      fprintf(stderr, "psi2N QP=%d iters=%.0f cycles/iter: stage %.0f prologue %.0f sweep %.0f red %.0f imbalance %.0f ycalc %.0f dzphases %.0f rowgrad %.0f\n", QP, a[6],
+      fprintf(stderr, "psi2N QP=%d iters=%.0f cycles/iter: stage %.0f prologue %.0f sweep %.0f red %.0f imbalance %.0f ycalc %.0f dz %.0f rowgrad %.0f\n", QP, a[6],
               a[0] / a[6], a[1] / a[6], a[2] / a[6], a[3] / a[6], hb[7] / a[6], th / a[6], a[4] / a[6], a[5] / a[6]);
     }
+#endif
     return hipSuccess;
   }
   if (fwd && bwd && psi2_use_rows4(a.M, QP)) {
