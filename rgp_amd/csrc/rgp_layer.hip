@@ -590,7 +590,7 @@ struct LayerWs {
 static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int D, int n_seq, LayerWs& L, SviChain* ch,
                           VarDtcChain* vc = nullptr) {
   WsAlloc ws(base);
-  const int QP = round_up(Q, 8);
+  const int QP = rgp_qp(Q);
   const size_t nq = (size_t)N * QP, nm = (size_t)N * M, nd = (size_t)N * (D > 0 ? D : 1);
   const int tri = M * (M + 1) / 2;
   L.nblk1 = NBLK1;
@@ -636,7 +636,7 @@ extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
 static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
   if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is not supported by this build");
-  if (round_up(Q, 8) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
+  if (rgp_qp(Q) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
   return RGP_OK;
 }
 

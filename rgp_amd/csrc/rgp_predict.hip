@@ -157,11 +157,11 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   if (!h) return RGP_ERR_BAD_ARG;
   const int X_dim = D;
   const int Q = X_win * X_dim + U_win * U_dim;
-  if (M > RGP_MAX_M || round_up(Q, 8) > RGP_MAX_QP || Q <= 0)
+  if (M > RGP_MAX_M || rgp_qp(Q) > RGP_MAX_QP || Q <= 0)
     return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 128 and 0 < Q <= 64 in this build");
   if (U_win > 0 && (!U_mean || u_rows - u_skip < steps + U_win - 1))
     return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: not enough input rows for the requested steps");
-  const int QP = round_up(Q, 8);
+  const int QP = rgp_qp(Q);
   // Z-derived terms in the handle's workspace
   rgp_status st;
   const size_t need = ((size_t)2 * QP + (size_t)M * QP + (size_t)QP * RGP_PSI2_TEAM + 2 * (size_t)M * M + 2) * sizeof(double) + 9 * 256;
@@ -180,6 +180,7 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   switch (QP) {
     case 8: freerun_launch<8>(h->stream, a); break;
     case 16: freerun_launch<16>(h->stream, a); break;
+    case 20: freerun_launch<20>(h->stream, a); break;
     case 24: freerun_launch<24>(h->stream, a); break;
     case 32: freerun_launch<32>(h->stream, a); break;
     case 40: freerun_launch<40>(h->stream, a); break;

@@ -272,7 +272,7 @@ void launch_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const Ro
   const int blocks = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   switch (zt.QP) {
 #define P1F(qp) case qp: hipLaunchKernelGGL((psi1_fwd_kernel<qp>), dim3(blocks), dim3(256), 0, s, N, M, zt.ZcT, rt.e1, rt.em, rt.g1, psi1); break;
-    P1F(8) P1F(16) P1F(24) P1F(32) P1F(40) P1F(48) P1F(56) P1F(64)
+    P1F(8) P1F(16) P1F(20) P1F(24) P1F(32) P1F(40) P1F(48) P1F(56) P1F(64)
 #undef P1F
     default: break;
   }
@@ -484,9 +484,10 @@ psi1_svi_fwd_kernel(const int64_t N, const int M, const int D, const double* __r
     __syncthreads();
     {                                             // branch-free staging: all loads of the tile are in flight together
       const int64_t lim = (int64_t)nr * QP - 1;
-      double2 v[QP / 8];
+      constexpr int NE = (P1_TILE * QP + 255) / 256;            // (e, e*mu) entries per thread
+      double2 v[NE];
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) {
+      for (int k = 0; k < NE; ++k) {
         const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
         v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
       }
@@ -494,7 +495,8 @@ psi1_svi_fwd_kernel(const int64_t N, const int M, const int D, const double* __r
       const double yv = (t < P1_TILE * DP && yd < D) ? Ym[(rb + yr) * D + (yd < D ? yd : 0)] : 0.0;
       const double gv = g1[rb + (t < nr ? t : nr - 1)];
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+      for (int k = 0; k < NE; ++k)
+        if (t + 256 * k < P1_TILE * QP) ee[t + 256 * k] = v[k];
       if (t < P1_TILE * DP) ys[t] = yv;
       if (DP > 8 && t + 256 < P1_TILE * DP) {
         const int i2 = t + 256, r2 = (i2 / DP < nr) ? i2 / DP : nr - 1, d2 = i2 % DP;
@@ -585,9 +587,10 @@ psi1_svi_fwd2_kernel(const int64_t N, const int M, const int D, const double* __
     __syncthreads();
     {
       const int64_t lim = (int64_t)nr * QP - 1;
-      double2 v[QP / 8];
+      constexpr int NE = (P1_TILE * QP + 255) / 256;            // (e, e*mu) entries per thread
+      double2 v[NE];
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) {
+      for (int k = 0; k < NE; ++k) {
         const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
         v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
       }
@@ -595,7 +598,8 @@ psi1_svi_fwd2_kernel(const int64_t N, const int M, const int D, const double* __
       const double yv = (t < P1_TILE * DP && yd < D) ? Ym[(rb + yr) * D + (yd < D ? yd : 0)] : 0.0;
       const double gv = g1[rb + (t < nr ? t : nr - 1)];
 #pragma unroll
-      for (int k = 0; k < QP / 8; ++k) ee[t + 256 * k] = v[k];
+      for (int k = 0; k < NE; ++k)
+        if (t + 256 * k < P1_TILE * QP) ee[t + 256 * k] = v[k];
       if (t < P1_TILE * DP) ys[t] = yv;
       if (t < P1_TILE) gs[t] = gv;
     }
@@ -668,7 +672,7 @@ template <int QP>
 __global__ void __launch_bounds__(256)
 psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
                    const double* __restrict__ em, const double* __restrict__ Lp, double* __restrict__ dz_part) {
-  constexpr int QW = QP / 4;                               // QP is a multiple of 8
+  constexpr int QW = QP / 4;                               // QP is a multiple of 4
   __shared__ __attribute__((aligned(16))) double buf[2 * P1Z_TILE * QP];
   __shared__ double lps[P1Z_TILE * RGP_PSI2_TEAM];
   double2* ee = reinterpret_cast<double2*>(buf);
@@ -915,7 +919,7 @@ void launch_psi1_svi(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms
     else psi1_svi_dispatch<qp, 16>(s, N, M, Q, D, zt, rt, Ym, Cpsi1, noise, P, Lp, psi1Y_part, gmu, gS, dYm, dlam_part, lsum_part, dz_part, nblk); \
     break;
   switch (zt.QP) {
-    P1S(8) P1S(16) P1S(24) P1S(32) P1S(40) P1S(48) P1S(56) P1S(64)
+    P1S(8) P1S(16) P1S(20) P1S(24) P1S(32) P1S(40) P1S(48) P1S(56) P1S(64)
     default: break;
   }
 #undef P1S
@@ -1280,7 +1284,7 @@ psi2_rows4_kernel(const int64_t N, const int M, const int Q, const double* __res
       }
     }
     // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab, q quarters rotated over the teams
-    constexpr int QQ = QP / 4;                           // QP is a multiple of 8
+    constexpr int QQ = QP / 4;                           // QP is a multiple of 4
 #pragma unroll 1
     for (int ph = 0; ph < 4; ++ph) {
       const int rq = (team + ph) & 3;
@@ -1760,6 +1764,7 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
   switch (zt.QP) {
     case 8:  e = psi2_dispatch<8>(s, fwd, bwd, a, nblk, !h->deterministic); break;
     case 16: e = psi2_dispatch<16>(s, fwd, bwd, a, nblk, !h->deterministic); break;
+    case 20: e = psi2_dispatch<20>(s, fwd, bwd, a, nblk, !h->deterministic); break;
     case 24: e = psi2_dispatch<24>(s, fwd, bwd, a, nblk, !h->deterministic); break;
     case 32: e = psi2_dispatch<32>(s, fwd, bwd, a, nblk, !h->deterministic); break;
     case 40: e = psi2_dispatch<40>(s, fwd, bwd, a, nblk, !h->deterministic); break;

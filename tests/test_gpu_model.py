@@ -169,6 +169,18 @@ def test_freerun_matches_oracle(inference):
     np.testing.assert_array_equal(both[-1][0][0].cpu().numpy(), got[-1][0][0].cpu().numpy())
 
 
+def test_freerun_padded_width_20():
+    """Free-run with a window of Q = 20 columns (the padded width 20 code path, as in the top layer of config 4)."""
+    o, g = build_pair(n_seq=2, T=40, wins=(0, 10), nDims=(2, 1), M=12, U_win=10, u_dim=1, y_dim=2)
+    compare(o, g)
+    U = np.random.default_rng(3).standard_normal((50, 1))
+    want, got = o.freerun(U), g.freerun(U)
+    g.handle.sync()
+    for (wm, wv), (gm, gv) in zip(want, got):
+        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
+
+
 def test_no_controls_and_wide_outputs():
     """U=None (the top layer sees only its own history, model.py:67-69) and a wide observed layer (D_y = 20, H = 2)."""
     from oracle import model as om
@@ -324,6 +336,7 @@ def test_collapsed_bound_data_parallel_two_shards():
     dict(n_seq=2, T=5, wins=(0, 2, 2), nDims=(2, 1, 1), M=2, U_win=1, u_dim=1, y_dim=2),     # shortest usable sequences, U_win = 1
     dict(n_seq=1, T=40, wins=(0, 8), nDims=(4, 4), M=128, U_win=8, u_dim=4, y_dim=4),         # maximum sizes: M = 128, Q = 64
     dict(n_seq=3, T=9, wins=(0, 1, 1), nDims=(1, 1, 1), M=3, U_win=1, u_dim=1, y_dim=1),      # windows of one step: Q = 2 / 1
+    dict(n_seq=2, T=30, wins=(0, 9, 3), nDims=(2, 2, 1), M=20, U_win=10, u_dim=1, y_dim=2),   # Q = 18 / 21 / 13: padded widths 20, 24, 16
 ])
 def test_edge_geometries(cfg, inference):
     """Minimal, degenerate and maximal geometries of the layer step (both bounds)."""
