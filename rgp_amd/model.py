@@ -342,6 +342,14 @@ class DeepAutoreg(object):
         h = self.handle
         self._flush_pipeline()
         ios, n_batch = self._build_ios(seqs, qU_ratio)
+        try:
+            return self._evaluate_ios(ios, n_batch, stats_allreduce, world)
+        except Exception:
+            h.discard_prepared()          # a failed call must not leave prepared layers queued for the next one
+            raise
+
+    def _evaluate_ios(self, ios, n_batch, stats_allreduce, world):
+        h = self.handle
         # start K_uu / factorisations / the data-independent SVI algebra of every layer now (side stream): they need only
         # the parameters, and would otherwise sit on the critical path in front of each layer's psi passes
         if self.svi and len(ios) <= 3:
@@ -531,7 +539,12 @@ class DeepAutoreg(object):
         ad, h = self._adam, self.handle
         pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate
         if pipelined:
-            elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo)
+            try:
+                elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo)
+            except Exception:
+                h.discard_prepared()
+                self._chain_ready = False
+                raise
         else:
             elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
             if allreduce is not None:
