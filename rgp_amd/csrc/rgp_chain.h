@@ -8,9 +8,9 @@ struct SviChain {
   const double *Kj, *noise, *qU_m, *qU_W, *qU_a;
   const double *psi0sum, *psi1Y, *psi2, *yry;          // stage 2 only
   // workspace (device, carved by svi_chain_carve)
-  double *Linv, *S, *Ls, *LsInv, *E, *EEt, *B, *A, *T1, *T2, *T3, *mA, *Kinv, *Gv;
+  double *Linv, *S, *LsInv, *B, *T1, *T2, *T3, *mA, *Kinv, *Gv;
   double *dLdpsi2, *dKmm;                               // results consumed by the psi backward / K backward
-  double *Sinv, *dKLdK;                                 // KL gradient terms, produced by stage 1b for stage 2
+  double *Sinv, *Wi;                                    // S^-1 and woodbury_inv, produced by stage 1c for stage 2
   double *gmu, *Kinv_mu, *Cpsi1, *Ybt, *gqm;
   double *scal, *bound, *dthetaL;
   // optional outputs (device, caller owned; may be null)

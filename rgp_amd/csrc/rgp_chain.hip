@@ -276,6 +276,37 @@ static __device__ void copy_out(double* g, const double* lds, int ld, int M) {
 // `pan` points at >= 2*GP_K*GP_LD doubles of LDS (the factorisation buffer is reused between factorisations).
 #define GP_K 32
 #define GP_LD 132
+#define GP_PE (GP_K * 128 / CH_THREADS)          // panel elements per thread
+
+// branch-free panel loads: all loads of a panel are issued before the first is consumed (a guarded load per element
+// compiled to a load -> wait -> store chain, one global-memory latency per element)
+template <bool TA>
+static __device__ __forceinline__ void gp_load_a(double (&va)[GP_PE], const double* __restrict__ A, int lda, int m, int k0, int kb) {
+#pragma unroll
+  for (int u = 0; u < GP_PE; ++u) {
+    const int e = threadIdx.x + u * CH_THREADS;
+    int kk, i;
+    if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }      // coalesced along the stored rows
+    const bool ok = kk < kb && i < m;
+    const int kc = ok ? k0 + kk : 0, ic = ok ? i : 0;
+    const double v = TA ? A[(size_t)kc * lda + ic] : A[(size_t)ic * lda + kc];
+    va[u] = ok ? v : 0.0;
+  }
+}
+template <bool TB>
+static __device__ __forceinline__ void gp_load_b(double (&vb)[GP_PE], const double* __restrict__ B, int ldb, int n, int k0, int kb) {
+#pragma unroll
+  for (int u = 0; u < GP_PE; ++u) {
+    const int e = threadIdx.x + u * CH_THREADS;
+    int kk, jx;
+    if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
+    const bool ok = kk < kb && jx < n;
+    const int kc = ok ? k0 + kk : 0, jc = ok ? jx : 0;
+    const double v = TB ? B[(size_t)jc * ldb + kc] : B[(size_t)kc * ldb + jc];
+    vb[u] = ok ? v : 0.0;
+  }
+}
+
 template <bool TA, bool TB>
 static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* __restrict__ A, int lda,
                                const double* __restrict__ B, int ldb, double beta, double* __restrict__ C, int ldc,
@@ -293,48 +324,32 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  double va[GP_PE], vb[GP_PE];
+  gp_load_a<TA>(va, A, lda, m, 0, k < GP_K ? k : GP_K);
+  gp_load_b<TB>(vb, B, ldb, n, 0, k < GP_K ? k : GP_K);
   for (int k0 = 0; k0 < k; k0 += GP_K) {
     const int kb = (k - k0 < GP_K) ? k - k0 : GP_K;
     __syncthreads();
-    // branch-free staging: all loads of the two panels are issued before the first is consumed (a guarded load per
-    // element compiled to a load -> wait -> store chain, one global-memory latency per element)
-    constexpr int PE = GP_K * 128 / CH_THREADS;          // panel elements per thread
-    double va[PE], vb[PE];
 #pragma unroll
-    for (int u = 0; u < PE; ++u) {
-      const int e = threadIdx.x + u * CH_THREADS;
-      int kk, i;
-      if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }      // coalesced along the stored rows
-      const bool ok = kk < kb && i < m;
-      const int kc = ok ? k0 + kk : 0, ic = ok ? i : 0;
-      const double v = TA ? A[(size_t)kc * lda + ic] : A[(size_t)ic * lda + kc];
-      va[u] = ok ? v : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < PE; ++u) {
-      const int e = threadIdx.x + u * CH_THREADS;
-      int kk, jx;
-      if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
-      const bool ok = kk < kb && jx < n;
-      const int kc = ok ? k0 + kk : 0, jc = ok ? jx : 0;
-      const double v = TB ? B[(size_t)jc * ldb + kc] : B[(size_t)kc * ldb + jc];
-      vb[u] = ok ? v : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < PE; ++u) {
+    for (int u = 0; u < GP_PE; ++u) {
       const int e = threadIdx.x + u * CH_THREADS;
       int kk, i;
       if (TA) { kk = e / 128; i = e % 128; } else { i = e / GP_K; kk = e % GP_K; }
       Ap[kk * GP_LD + i] = va[u];
     }
 #pragma unroll
-    for (int u = 0; u < PE; ++u) {
+    for (int u = 0; u < GP_PE; ++u) {
       const int e = threadIdx.x + u * CH_THREADS;
       int kk, jx;
       if (TB) { jx = e / GP_K; kk = e % GP_K; } else { kk = e / 128; jx = e % 128; }
       Bp[kk * GP_LD + jx] = vb[u];
     }
     __syncthreads();
+    if (k0 + GP_K < k) {               // the next panel's loads stay in flight under this panel's arithmetic
+      const int kn = (k - k0 - GP_K < GP_K) ? k - k0 - GP_K : GP_K;
+      gp_load_a<TA>(va, A, lda, m, k0 + GP_K, kn);
+      gp_load_b<TB>(vb, B, ldb, n, k0 + GP_K, kn);
+    }
     if (has) {
 #pragma unroll 4
       for (int kk = 0; kk < kb; ++kk) {
@@ -365,6 +380,21 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
   __syncthreads();
 }
 
+// ==================================================================================================================
+// SVI chain.  The reference's expressions (svi_vardtc.py:95-169, 205-213) are evaluated in an algebraically equal form
+// that needs 11 instead of 20 M x M x M products; with Kinv = Linv^T Linv, V = mu mu^T + D S, B = Linv V Linv^T:
+//   dL_dpsi2 = beta/2 Linv^T (D I - B) Linv                         (:169, kept in the reference's sandwich form: the
+//                                                                    difference D I - B is formed before the congruence)
+//   -1/2 sum(B o A) + D/2 tr A  = sum(dL_dpsi2 o psi2)              (:113-123, A = beta Linv psi2 Linv^T never formed)
+//   sum(gmu o Ybt)              = sum(Cpsi1 o psi1Y^T)
+//   mA = -Linv^T A Linv         = -beta Kinv psi2 Kinv              (:145)
+//   1/2 (t1 + t1^T) - D/2 Linv^T A Linv = -(R + R^T) - D/2 mA,  R = dL_dpsi2 psi2 Kinv      (:129-133)
+//   Linv^T (gmu Ybt^T) Linv     = Kinv_mu Vt^T,  Vt = beta Kinv psi1Y^T
+//   dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv = dL_dpsi2 / beta           (:213)
+//   D/2 ||E||_F^2 + 1/2 ||gmu||_F^2 = 1/2 tr B                      (:209)
+//   woodbury_inv = Linv^T (I - E E^T) Linv = (2 / (beta D)) dL_dpsi2 + Kinv_mu Kinv_mu^T / D     (:154)
+// ==================================================================================================================
+
 // ---- stage 1a: K_uu factor and dL/dpsi1 coefficients (what the psi1 passes wait for) -------------------------------
 __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_a_kernel(SviChain c) {
   extern __shared__ double lds[];
@@ -389,49 +419,51 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_a_kernel(SviChain c)
 __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c) {
   extern __shared__ double lds[];
   __shared__ double scratch[16];
-  const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
+  const int M = c.M, D = c.D, t = threadIdx.x;
   const double Dd = (double)D;
   const double beta = 1.0 / c.noise[0];
-  // S = W W^T + a I ; Ls                                          (layers.py:71, svi_vardtc.py:95)
+  // S = W W^T + a I                                               (layers.py:71)
   wg_gemm<false, true>(M, M, M, 1.0, c.qU_W, M, c.qU_W, M, 0.0, c.S, M, lds);
-  if (t < M) c.S[t * M + t] += c.qU_a[0];
+  const double qa = c.qU_a[0];
+  // V = D S + mu mu^T
+  for (int i = t; i < M * M; i += blockDim.x) {
+    const double sv = c.S[i] + ((i / M == i % M) ? qa : 0.0);
+    c.S[i] = sv;
+    c.T1[i] = Dd * sv;
+  }
   __syncthreads();
-  copy_in(lds, ld, c.S, M);
-  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);
-  double lds_ = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
-  copy_out(c.Ls, lds, ld, M);
-  // E = Linv Ls                                                   (svi_vardtc.py:96)
-  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.Ls, M, 0.0, c.E, M, lds);
-  // B = D E E^T + gmu gmu^T                                       (:111)
-  wg_gemm<false, true>(M, M, M, 1.0, c.E, M, c.E, M, 0.0, c.EEt, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.B[i] = Dd * c.EEt[i];
-  __syncthreads();
-  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.gmu, D, 1.0, c.B, M, lds);
+  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T1, M, lds);
+  // B = Linv V Linv^T  ( = D E E^T + gmu gmu^T, :111)
+  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.T1, M, 0.0, c.T2, M, lds);
+  wg_gemm<false, true>(M, M, M, 1.0, c.T2, M, c.Linv, M, 0.0, c.B, M, lds);
   // dL_dpsi2 = beta/2 Linv^T (D I - B) Linv                       (:169), symmetric by construction
   for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? Dd : 0.0) - c.B[i];
   __syncthreads();
   wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
   wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
-  if (t == 0) c.scal[1] = lds_;     // sum log diag Ls
+  const double trB = block_sum((t < M) ? c.B[t * M + t] : 0.0, scratch);
+  if (t == 0) c.scal[2] = trB;      // D ||E||^2 + ||gmu||^2
 }
 
-// ---- stage 1c: KL gradient terms (:211-213), independent of the statistics, needed only by stage 2 -----------------
-//   LsInv, Kinv = Linv^T Linv, Sinv = LsInv^T LsInv, V = mu mu^T + D S, dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv
+// ---- stage 1c: what only stage 2 needs: log det S, Kinv, Sinv (:205-213) and the posterior's woodbury_inv (:154) ----
 __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_c_kernel(SviChain c) {
   extern __shared__ double lds[];
+  __shared__ double scratch[16];
   const int M = c.M, D = c.D, ld = M + 1, t = threadIdx.x;
   const double Dd = (double)D;
-  copy_in(lds, ld, c.Ls, M);
+  const double beta = 1.0 / c.noise[0];
+  copy_in(lds, ld, c.S, M);
+  lds_chol_blocked(lds, M, ld, c.status, lds + (size_t)M * ld);                    // Ls (svi_vardtc.py:95)
+  double lds_ = block_sum((t < M) ? log(lds[t * ld + t]) : 0.0, scratch);
   lds_trtri_blocked(lds, M, ld, lds + (size_t)M * ld);
   copy_out(c.LsInv, lds, ld, M);
   wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, c.Kinv, M, lds);
   wg_gemm<true, false>(M, M, M, 1.0, c.LsInv, M, c.LsInv, M, 0.0, c.Sinv, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.T2[i] = Dd * c.S[i];
+  // woodbury_inv (see the identities above)
+  for (int i = t; i < M * M; i += blockDim.x) c.Wi[i] = 2.0 / (beta * Dd) * c.dLdpsi2[i];
   __syncthreads();
-  wg_gemm<false, true>(M, M, D, 1.0, c.qU_m, D, c.qU_m, D, 1.0, c.T2, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Kinv, M, 0.0, c.T1, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, c.Kinv, M, c.T1, M, 0.0, c.T3, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.dKLdK[i] = 0.5 * Dd * c.Kinv[i] - 0.5 * c.T3[i];
+  wg_gemm<false, true>(M, M, D, 1.0 / Dd, c.Kinv_mu, D, c.Kinv_mu, D, 1.0, c.Wi, M, lds);
+  if (t == 0) c.scal[1] = lds_;     // sum log diag Ls
 }
 
 // ---- stage 2: after the statistics are known --------------------------------------------------------------------
@@ -442,51 +474,32 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   const double Dd = (double)D, Nd = (double)c.N;
   const double beta = 1.0 / c.noise[0];
   const double ratio = c.qU_ratio;
-  // A = beta Linv psi2 Linv^T                                     (:107)
-  wg_gemm<false, false>(M, M, M, 1.0, c.Linv, M, c.psi2, M, 0.0, c.T1, M, lds);
-  wg_gemm<false, true>(M, M, M, beta, c.T1, M, c.Linv, M, 0.0, c.A, M, lds);
-  // Ybt (M x D) = beta Linv psi1Y^T                               (:98)
-  wg_gemm<false, true>(M, D, M, beta, c.Linv, M, c.psi1Y, M, 0.0, c.Ybt, D, lds);
-  double sBA = 0.0, trA = 0.0, gY = 0.0, e2 = 0.0, g2 = 0.0;
-  for (int i = t; i < M * M; i += blockDim.x) {
-    sBA += c.B[i] * c.A[i];
-    if (i / M == i % M) trA += c.A[i];
-    e2 += c.E[i] * c.E[i];
-  }
-  for (int i = t; i < M * D; i += blockDim.x) {
-    gY += c.gmu[i] * c.Ybt[i];
-    g2 += c.gmu[i] * c.gmu[i];
-  }
-  sBA = block_sum(sBA, scratch); trA = block_sum(trA, scratch); gY = block_sum(gY, scratch);
-  e2 = block_sum(e2, scratch); g2 = block_sum(g2, scratch);
-  const double data_fit = -0.5 * Dd * beta * c.psi0sum[0] - 0.5 * beta * c.yry[0] - 0.5 * sBA + 0.5 * Dd * trA + gY;
+  // X = psi2 Kinv ;  mA = -beta Kinv X ;  R = dL_dpsi2 X
+  wg_gemm<false, false>(M, M, M, 1.0, c.psi2, M, c.Kinv, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, false>(M, M, M, -beta, c.Kinv, M, c.T1, M, 0.0, c.mA, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.dLdpsi2, M, c.T1, M, 0.0, c.T2, M, lds);
+  // Vt (M x D) = beta Kinv psi1Y^T ;  Wm = Kinv_mu Vt^T
+  wg_gemm<false, true>(M, D, M, beta, c.Kinv, M, c.psi1Y, M, 0.0, c.Ybt, D, lds);
+  wg_gemm<false, true>(M, M, D, 1.0, c.Kinv_mu, D, c.Ybt, D, 0.0, c.T3, M, lds);
+  double sP = 0.0, gY = 0.0;
+  for (int i = t; i < M * M; i += blockDim.x) sP += c.dLdpsi2[i] * c.psi2[i];
+  for (int i = t; i < M * D; i += blockDim.x) gY += c.Cpsi1[i] * c.psi1Y[(size_t)(i % D) * M + i / D];
+  sP = block_sum(sP, scratch); gY = block_sum(gY, scratch);
+  const double data_fit = -0.5 * Dd * beta * c.psi0sum[0] - 0.5 * beta * c.yry[0] + sP + gY;
   const double logL = -0.5 * Nd * Dd * LOG_2PI + 0.5 * Dd * Nd * log(beta) + data_fit;            // :121-123
   const double dthetaL = -0.5 * Dd * Nd * beta - data_fit * beta;                                   // :139
-  const double KL = -0.5 * Dd * M - Dd * c.scal[1] + Dd * c.scal[0] + 0.5 * Dd * e2 + 0.5 * g2;      // :209
-  // dL_dKmm = 1/2 (t1 + t1^T) + t3,  t1 = Linv^T B A Linv,  t3 = 1/2 Linv^T (-D A - t2 - t2^T) Linv   (:129-133)
-  wg_gemm<false, false>(M, M, M, 1.0, c.B, M, c.A, M, 0.0, c.T1, M, lds);          // B A
-  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.Ybt, D, 0.0, c.T2, M, lds);       // t2 = gmu Ybar
+  const double KL = -0.5 * Dd * M - Dd * c.scal[1] + Dd * c.scal[0] + 0.5 * c.scal[2];               // :209
+  // dL_dKmm (:129-133) minus ratio dKL_dK (:213);  dL_dqU_mean = mA mu + Vt (:146);  dL_dqU_var = D/2 mA (:147)
+  const double rb = ratio / beta;
   for (int i = t; i < M * M; i += blockDim.x) {
-    const int r = i / M, cc = i % M;
-    // U = 1/2 (BA + (BA)^T) + 1/2 (-D A - t2 - t2^T): everything that is sandwiched by Linv^T . Linv
-    c.T3[i] = 0.5 * (c.T1[i] + c.T1[cc * M + r]) + 0.5 * (-Dd * c.A[i] - c.T2[i] - c.T2[cc * M + r]);
-  }
-  __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T1, M, lds);
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T1, M, 0.0, c.dKmm, M, lds);
-  // mA = -Linv^T A Linv ; dL_dqU_mean = mA mu + Linv^T Ybt ; dL_dqU_var = D/2 mA      (:145-147)
-  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T1, M, lds);
-  wg_gemm<true, false>(M, M, M, -1.0, c.Linv, M, c.T1, M, 0.0, c.mA, M, lds);
-  wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 0.0, c.gqm, D, lds);
-  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.Ybt, D, 1.0, c.gqm, D, lds);
-  // KL gradients (:211-213) with Kinv, Sinv and dKL_dK from stage 1b
-  // Gv = dL_dqU_var - ratio dKL_dvar = D/2 mA - ratio D/2 (Kinv - Sinv)
-  for (int i = t; i < M * M; i += blockDim.x) {
+    const int r = i / M, cc = i % M, it = cc * M + r;
+    c.dKmm[i] = -(c.T2[i] + c.T2[it]) - 0.25 * Dd * (c.mA[i] + c.mA[it]) - 0.5 * (c.T3[i] + c.T3[it]) - rb * c.dLdpsi2[i];
+    // Gv = dL_dqU_var - ratio dKL_dvar = D/2 mA - ratio D/2 (Kinv - Sinv)
     c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);
-    c.dKmm[i] -= ratio * c.dKLdK[i];
   }
-  for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] -= ratio * c.Kinv_mu[i];
+  for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] = c.Ybt[i] - ratio * c.Kinv_mu[i];
   __syncthreads();
+  wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 1.0, c.gqm, D, lds);
   // q(U) parameter gradients (layers.py:173-176)
   if (c.gqU_m) for (int i = t; i < M * D; i += blockDim.x) c.gqU_m[i] = c.gqm[i];
   if (c.gqU_W) {
@@ -494,13 +507,7 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
     __syncthreads();
     wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.qU_W, M, 0.0, c.gqU_W, M, lds);
   }
-  // woodbury_inv = Linv^T (I - E E^T) Linv                        (:154)
-  if (c.winv) {
-    for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = ((i / M == i % M) ? 1.0 : 0.0) - c.EEt[i];
-    __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
-    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
-  }
+  if (c.winv) for (int i = t; i < M * M; i += blockDim.x) c.winv[i] = c.Wi[i];
   double tr = block_sum((t < M) ? c.Gv[t * M + t] : 0.0, scratch);
   if (t == 0) {
     if (c.gqU_a) c.gqU_a[0] = tr;
@@ -515,11 +522,10 @@ size_t svi_chain_ws_doubles(int M, int D) {
 
 void svi_chain_carve(SviChain& c, WsAlloc& ws) {
   const size_t mm = (size_t)c.M * c.M, md = (size_t)c.M * c.D;
-  c.Linv = ws.take<double>(mm); c.S = ws.take<double>(mm); c.Ls = ws.take<double>(mm); c.LsInv = ws.take<double>(mm);
-  c.E = ws.take<double>(mm); c.EEt = ws.take<double>(mm); c.B = ws.take<double>(mm); c.A = ws.take<double>(mm);
+  c.Linv = ws.take<double>(mm); c.S = ws.take<double>(mm); c.LsInv = ws.take<double>(mm); c.B = ws.take<double>(mm);
   c.T1 = ws.take<double>(mm); c.T2 = ws.take<double>(mm); c.T3 = ws.take<double>(mm); c.mA = ws.take<double>(mm);
   c.Kinv = ws.take<double>(mm); c.Gv = ws.take<double>(mm); c.dLdpsi2 = ws.take<double>(mm); c.dKmm = ws.take<double>(mm);
-  c.Sinv = ws.take<double>(mm); c.dKLdK = ws.take<double>(mm);
+  c.Sinv = ws.take<double>(mm); c.Wi = ws.take<double>(mm);
   c.gmu = ws.take<double>(md); c.Kinv_mu = ws.take<double>(md); c.Cpsi1 = ws.take<double>(md); c.Ybt = ws.take<double>(md);
   c.gqm = ws.take<double>(md);
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1);

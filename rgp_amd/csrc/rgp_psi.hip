@@ -1671,6 +1671,7 @@ Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   if (nt >= 4) {
     int64_t g = h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0);     // one 512-thread workgroup per CU, nt rows in flight;
                                                                           // one CU stays free for the side-stream M x M chains
+    { static int env_g = -1; if (env_g < 0) { const char* e = getenv("RGP_PSI2_GRID"); env_g = e ? atoi(e) : 0; } if (env_g > 0) g = env_g; }
     if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
     pl.grid = (int)(g < 1 ? 1 : g);
     pl.n_p2 = pl.grid; pl.n_dz = pl.grid; pl.n_dl = nt * pl.grid;

@@ -106,6 +106,44 @@ def test_svi_chain_against_reference_fixture(H, path):
     assert rel(c('gqU_a'), np.trace(Gv).reshape(1)) < 1e-9
 
 
+@pytest.mark.parametrize('spread,tol', [(1.0, 1e-11), (0.3, 1e-8)])
+def test_svi_chain_m100_against_oracle(H, spread, tol):
+    """M = 100 (the benchmark's size) with a well and an ill conditioned K_uu (cond ~ 4e3 / 5e6): the device chain evaluates
+    the reference's expressions in a reduced form (rgp_chain.hip header), so it is checked against the solve-based oracle
+    where rounding differences would show; the tolerance scales with eps * cond(K_uu)."""
+    from oracle import inference as inf, psi_stats as ps
+    rng = np.random.default_rng(7)
+    M, Q, D, N = 100, 12, 16, 600
+    Z = rng.standard_normal((M, Q)) * spread
+    il, var, noise = np.full(Q, 0.3), 1.3, 0.05
+    mu = rng.standard_normal((N, Q)) * spread
+    S = 0.05 + 0.1 * rng.random((N, Q))
+    P = ps.PsiStatsFast(64)
+    psi1, psi2 = P.psi1(var, il, Z, mu, S), P.psi2(var, il, Z, mu, S)
+    Kuu = var * np.exp(-0.5 * (((Z[:, None] - Z[None]) * il) ** 2).sum(-1))
+    Y = rng.standard_normal((N, D))
+    qm, W, a = rng.standard_normal((M, D)), 0.3 * rng.standard_normal((M, M)), 0.5
+    qS = W.dot(W.T) + a * np.eye(M)
+    st = inf.Stats(N * var, psi1, psi2, Y)
+    logL, g, winv, wvec, mid = inf.svi(Kuu, st, noise, qm, qS)
+    KL, dKLm, dKLv, dKLK = inf.kl_qU(qm, qS, mid)
+    ratio = 0.37
+    o = H.svi_chain(N, dev(H, Kuu + 1e-6 * np.eye(M)), dev(H, [noise]), dev(H, qm), dev(H, W), dev(H, [a]), dev(H, [N * var]),
+                    dev(H, Y.T.dot(psi1)), dev(H, psi2), dev(H, [(Y ** 2).sum()]), qU_ratio=ratio)
+    H.sync()
+    c = lambda k: o[k].cpu().numpy()
+    Gv = g['dL_dqU_var'] - ratio * dKLv
+    assert abs(c('bound')[0] - (logL - ratio * KL)) < tol * abs(logL)
+    assert rel(c('dL_dKmm'), g['dL_dKmm'] - ratio * dKLK) < tol
+    assert rel(c('dL_dpsi2'), g['dL_dpsi2']) < tol
+    assert rel(c('Kinv_mu'), wvec) < tol
+    assert rel(c('woodbury_inv'), winv) < tol
+    assert rel(c('dL_dthetaL'), np.asarray(g['dL_dthetaL']).reshape(1)) < tol
+    assert rel(c('gqU_m'), g['dL_dqU_mean'] - ratio * dKLm) < tol
+    assert rel(c('gqU_W'), (Gv + Gv.T).dot(W)) < tol
+    assert rel(c('gqU_a'), np.trace(Gv).reshape(1)) < tol
+
+
 def test_not_pd_is_reported(H):
     from rgp_amd._lib import RgpError
     M, D = 4, 1
