@@ -5,6 +5,9 @@
 
 #include "rgp_chain.h"
 #include "rgp_psi.h"
+#ifdef RGP_GAPPROF
+void rgp_gap_dump();
+#endif
 
 // ==================================================================================================================
 // handle
@@ -109,6 +112,9 @@ extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
   int st[2] = {0, 0};
   rgp_join_streams(h);
   RGP_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+#ifdef RGP_GAPPROF
+  rgp_gap_dump();
+#endif
   RGP_HIP_CHECK(h, hipMemcpy(st, h->status, sizeof(st), hipMemcpyDeviceToHost));
   if (st[0] != 0) {
     hipMemset(h->status, 0, 2 * sizeof(int));
@@ -147,6 +153,35 @@ extern "C" rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* ps
   if (reset) { h->prof_used = 0; h->prof_nmmq = 0.0; }
   return RGP_OK;
 }
+
+#ifdef RGP_GAPPROF      // profiling builds only (make CXXFLAGS+=-DRGP_GAPPROF): where the main stream waits inside a layer step
+#include <chrono>
+struct GapRec { hipEvent_t e[4]; double host_us; };
+static std::vector<GapRec> g_gap;
+static void gap_mark(rgp_handle h, int k, bool first) {
+  if (first) {
+    GapRec r{};
+    for (auto& e : r.e) (void)hipEventCreate(&e);
+    r.host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    g_gap.push_back(r);
+  }
+  (void)hipEventRecord(g_gap.back().e[k], h->stream);
+}
+void rgp_gap_dump() {
+  const size_t n = g_gap.size();
+  if (n < 14) return;
+  const size_t a = n - 13;
+  for (size_t i = a; i < n; ++i) {
+    float t[4];
+    for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], g_gap[a].e[0], g_gap[i].e[k]);
+    fprintf(stderr, "[gap] call %zu host %+9.1f us | main reaches step %9.1f, rows+pre_a ready %9.1f, pre_b ready %9.1f, main work done %9.1f us\n",
+            i - a, g_gap[i].host_us - g_gap[a].host_us, t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, t[3] * 1e3);
+  }
+}
+#define GAP_MARK(k, first) gap_mark(h, k, first)
+#else
+#define GAP_MARK(k, first) do { } while (0)
+#endif
 
 static void prof_begin(rgp_handle h, double nmmq) {
   if (!h->profiling) return;
@@ -1090,6 +1125,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // the window tables and row terms were produced by svi_prepare_slot (side_rows stream)
   WindowSpec w = svi_window_spec(in, L);
+  GAP_MARK(0, true);
   if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_rows[slot], 0));
 
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
@@ -1099,6 +1135,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   // psi1 side
   if (psi1_svi_supported(D)) {
     if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_a[slot], 0));  // Cpsi1 comes from the chain's first kernel
+    GAP_MARK(1, false);
     launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
                     in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
     const int rb = psi1_svi_rows_blocks(N);
@@ -1126,6 +1163,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
   if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_b[slot], 0));    // dL_dpsi2 comes from the chain's second kernel
+  GAP_MARK(2, false);
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
   {
     Psi2Out o{};
@@ -1161,6 +1199,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
     hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
   }
+  GAP_MARK(3, false);
   // data-dependent algebra + kernel-hyperparameter gradients on the side stream: overlaps the next layer's psi passes
   if (h->overlap) {
     RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));

@@ -1671,7 +1671,19 @@ Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   if (nt >= 4) {
     int64_t g = h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0);     // one 512-thread workgroup per CU, nt rows in flight;
                                                                           // one CU stays free for the side-stream M x M chains
-    { static int env_g = -1; if (env_g < 0) { const char* e = getenv("RGP_PSI2_GRID"); env_g = e ? atoi(e) : 0; } if (env_g > 0) g = env_g; }
+    // Short passes leave CUs free in every XCD.  A workgroup of the psi2 pass owns its CU (LDS and registers), so a side-stream
+    // kernel can only start on a CU without one; the dispatcher hands each new kernel's first workgroup to the next XCD of a
+    // global round-robin (tools/coresidency_probe.hip), so a single-workgroup M x M chain kernel whose turn falls on a full XCD
+    // waits for a psi2 workgroup to drain -- the whole pass.  With 8 x 29 workgroups the chains of the other layers never
+    // wait; the fewer sweeps a workgroup has, the more that latency matters and the less the idle CUs cost
+    // (profiles/r1_grid_ab.txt: +19 % per step at 2 sequences per rank, +10 % at 4, +5 % at 8, +3 % at 16).
+    if (h->overlap && h->num_cu == 256) {
+      const int64_t sweeps = (N + g * nt - 1) / (g * nt);
+      if (sweeps <= 16) g = 232;
+      else if (sweeps <= 32) g = 240;
+      else if (sweeps <= 64) g = 248;
+    }
+    { static int env_g = -1; if (env_g < 0) { const char* e = getenv("RGP_PSI2_GRID"); env_g = e ? atoi(e) : 0; } if (env_g > 0) g = env_g; }   // tuning override
     if (g > (N + nt - 1) / nt) g = (N + nt - 1) / nt;
     pl.grid = (int)(g < 1 ? 1 : g);
     pl.n_p2 = pl.grid; pl.n_dz = pl.grid; pl.n_dl = nt * pl.grid;
