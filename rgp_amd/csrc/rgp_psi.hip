@@ -1679,6 +1679,8 @@ Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
     // (profiles/r1_grid_ab.txt: +19 % per step at 2 sequences per rank, +10 % at 4, +5 % at 8, +3 % at 16).
     if (h->overlap && h->num_cu == 256) {
       const int64_t sweeps = (N + g * nt - 1) / (g * nt);
+      // multiples of 8 only: 233 workgroups (one sweep fewer at 4 sequences per rank) run 13 % slower per step than 232, because
+      // the dispatcher's round-robin position then moves on by the remainder after every pass
       if (sweeps <= 16) g = 232;
       else if (sweeps <= 32) g = 240;
       else if (sweeps <= 64) g = 248;
