@@ -186,6 +186,37 @@ rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_win, int U_w
                        const double* U_mean, const double* U_var, double u_var_const, int64_t u_rows, int64_t u_skip,
                        double* X_mean, double* X_var);
 
+/* ---- MLP back-constraint recursion as a per-sequence persistent scan --------------------------------------------
+ * Replaces Layer._encoder_freerun (autoreg/layers.py:623-666) and the reverse loop of Layer._encoder_update_gradient
+ * (layers.py:668-756) for the network of autoreg/mlp.py:13-175 (tanh hidden layers, linear output):
+ *     mean[X_win+n] = MLP([mean[n..n+X_win) | up[u_off+n .. u_off+n+U_win)]),  n = 0..N-1,  u_off = up_len - N - U_win + 1.
+ * One workgroup per sequence; all n_seq sequences have the same lengths.  dims[0] = X_win*X_dim + U_win*U_dim,
+ * dims[n_layers] = X_dim; W[k] is dims[k+1] x dims[k] row-major (out x in), b[k] dims[k+1].
+ * Layouts: init_mean [n_seq][X_win][X_dim]; up [n_seq][up_len][U_dim] (NULL iff U_win == 0); mean [n_seq][X_win+N][X_dim];
+ * act[k] [n_seq][N][dims[k+1]] for the hidden layers k < n_layers-1 (written by the forward, read by the backward).
+ * Backward: g_mean [n_seq][X_win+N][X_dim] = dL/d mean from the GP layers (rgp_layer_step) -> g_init [n_seq][X_win][X_dim]
+ * (gradient of the first rows), g_up [n_seq][up_len][U_dim] (gradient of the signal above; may be NULL) and
+ * delta[k] [n_seq][N][dims[k+1]] = dL/d(pre-activation of layer k at step n); the weight gradients are
+ * dW[k] = sum_{seq,n} delta[k] in_k^T, db[k] = sum delta[k] (GEMMs over stored activations, done by the caller). */
+#define RGP_MLP_MAX_LAYERS 4
+typedef struct rgp_mlp_scan {
+  int32_t n_seq, X_win, X_dim, U_win, U_dim, N, up_len, n_layers;
+  int32_t dims[RGP_MLP_MAX_LAYERS + 1];
+  int32_t reserved[3];
+  const double* W[RGP_MLP_MAX_LAYERS];
+  const double* b[RGP_MLP_MAX_LAYERS];
+  const double* init_mean;
+  const double* up;
+  double* mean;                              /* forward output */
+  double* act[RGP_MLP_MAX_LAYERS - 1];       /* forward output / backward input */
+  const double* g_mean;                      /* backward input */
+  double* g_init;                            /* backward outputs */
+  double* g_up;
+  double* delta[RGP_MLP_MAX_LAYERS];
+} rgp_mlp_scan;
+rgp_status rgp_mlp_scan_forward(rgp_handle h, const rgp_mlp_scan* a);
+rgp_status rgp_mlp_scan_backward(rgp_handle h, const rgp_mlp_scan* a);
+
 /* ---- optimiser step on device (the outer SVI loop's Adam; positive parameters live in softplus space) -------- */
 /* x, m, v: n doubles of optimiser-space parameter and Adam moments; g: gradient w.r.t. the CONSTRAINED value p;
  * positive[i] != 0 -> p = softplus(x) and the chain factor 1-exp(-p) is applied (paramz Logexp).  The new constrained

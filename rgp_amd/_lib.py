@@ -33,6 +33,18 @@ class LayerOut(C.Structure):
                 ('woodbury_inv', c_dp), ('woodbury_vector', c_dp)]
 
 
+MLP_MAX_LAYERS = 4
+
+
+class MlpScan(C.Structure):
+    _fields_ = [('n_seq', C.c_int32), ('X_win', C.c_int32), ('X_dim', C.c_int32), ('U_win', C.c_int32), ('U_dim', C.c_int32),
+                ('N', C.c_int32), ('up_len', C.c_int32), ('n_layers', C.c_int32),
+                ('dims', C.c_int32 * (MLP_MAX_LAYERS + 1)), ('reserved', C.c_int32 * 3),
+                ('W', c_dp * MLP_MAX_LAYERS), ('b', c_dp * MLP_MAX_LAYERS),
+                ('init_mean', c_dp), ('up', c_dp), ('mean', c_dp), ('act', c_dp * (MLP_MAX_LAYERS - 1)),
+                ('g_mean', c_dp), ('g_init', c_dp), ('g_up', c_dp), ('delta', c_dp * MLP_MAX_LAYERS)]
+
+
 # every symbol include/rgp_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     'rgp_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
@@ -61,6 +73,8 @@ SYMBOLS = {
                                      C.c_double, C.c_double, C.c_int64]),
     'rgp_discard_prepared': (C.c_int, [C.c_void_p]),
     'rgp_get_stream': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    'rgp_mlp_scan_forward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
+    'rgp_mlp_scan_backward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
 }
 PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY = 1, 2          # rgp_layer_in.reserved for rgp_layer_prepare
 

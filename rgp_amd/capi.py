@@ -162,5 +162,48 @@ class Handle(object):
                                            float(lr), float(beta1), float(beta2), float(eps), int(step)))
 
 
+def _mlp_args(spec, dims, n_seq, Ws, bs, init_mean=None, up=None, mean=None, acts=(), g_mean=None, g_init=None, g_up=None, deltas=()):
+    a = _lib.MlpScan()
+    a.n_seq, a.X_win, a.X_dim, a.U_win, a.U_dim = n_seq, spec['X_win'], spec['X_dim'], spec['U_win'], spec['U_dim']
+    a.N, a.up_len, a.n_layers = spec['N'], (0 if up is None else up.shape[1]), len(Ws)
+    for k, v in enumerate(dims):
+        a.dims[k] = v
+    for k, (W, b) in enumerate(zip(Ws, bs)):
+        _chk64(W, b)
+        a.W[k], a.b[k] = W.data_ptr(), b.data_ptr()
+    for k, t in enumerate(acts):
+        a.act[k] = t.data_ptr()
+    for k, t in enumerate(deltas):
+        a.delta[k] = t.data_ptr()
+    for name, t in (('init_mean', init_mean), ('up', up), ('mean', mean), ('g_mean', g_mean), ('g_init', g_init), ('g_up', g_up)):
+        if t is not None:
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64
+            setattr(a, name, t.data_ptr())
+    return a
+
+
+def mlp_scan_forward(handle, spec, dims, init_mean, up, Ws, bs):
+    """rgp_mlp_scan_forward: returns (mean (B, X_win+N, X_dim), [hidden activations (B, N, dims[k+1])])."""
+    if len(Ws) > _lib.MLP_MAX_LAYERS:
+        raise RgpError(_lib.RGP_ERR_BAD_ARG, 'mlp scan: at most %d linear layers' % _lib.MLP_MAX_LAYERS)
+    B = init_mean.shape[0]
+    mean = handle.new(B, spec['X_win'] + spec['N'], spec['X_dim'])
+    acts = [handle.new(B, spec['N'], dims[k + 1]) for k in range(len(Ws) - 1)]
+    a = _mlp_args(spec, dims, B, Ws, bs, init_mean=init_mean, up=up, mean=mean, acts=acts)
+    handle._check(handle.lib.rgp_mlp_scan_forward(handle.h, C.byref(a)))
+    return mean, acts
+
+
+def mlp_scan_backward(handle, spec, dims, up, Ws, bs, acts, g_mean, want_g_up):
+    """rgp_mlp_scan_backward: returns (g_init (B, X_win, X_dim), g_up or None, [delta_k (B, N, dims[k+1])])."""
+    B = g_mean.shape[0]
+    g_init = handle.new(B, spec['X_win'], spec['X_dim'])
+    g_up = handle.new(*up.shape) if (want_g_up and up is not None) else None
+    deltas = [handle.new(B, spec['N'], dims[k + 1]) for k in range(len(Ws))]
+    a = _mlp_args(spec, dims, B, Ws, bs, up=up, acts=acts, g_mean=g_mean, g_init=g_init, g_up=g_up, deltas=deltas)
+    handle._check(handle.lib.rgp_mlp_scan_backward(handle.h, C.byref(a)))
+    return g_init, g_up, deltas
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()

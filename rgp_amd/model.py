@@ -801,6 +801,7 @@ class DeepAutoreg_mlp(DeepAutoreg):
             specs.append(dict(index=i, X_win=L.X_win, X_dim=L.X_dim, U_win=L.U_win, U_dim=L.U_dim,
                               N=int(self.lat_len[i][0]) - L.X_win, up_len=up_len))
         self.encoder = MlpBackConstraint(specs, self.nSeq, X_variance=X_variance, MLP_dims=MLP_dims).to(self.device)
+        self.encoder.handle = self.handle                                        # the recursion runs as a device scan
         self.controls = None if Us is None else self.Ucat.view(self.nSeq, int(self.u_len[0]), self.Du)
         self._enc_index = {}
         for sp in specs:

@@ -125,3 +125,47 @@ def test_minibatch_additivity_and_svi_progress():
     e3 = float(m.evaluate().item())
     m.handle.sync()
     assert np.isfinite(e3) and e3 > e0, (e0, e3)
+
+
+@pytest.mark.parametrize('dims_mid,Xw,Xd,Uw,Ud,N', [((7, 5), 3, 2, 2, 3, 11), ((16,), 1, 1, 0, 0, 9), ((9, 6, 4), 2, 3, 4, 1, 40),
+                                                     ((80, 41), 20, 1, 20, 1, 300)])
+def test_scan_kernels_match_torch_graph(dims_mid, Xw, Xd, Uw, Ud, N):
+    """rgp_mlp_scan_forward/_backward against the same recursion written as a PyTorch graph (one network call per step) and
+    torch.autograd: means, gradients of the first rows, of the signal above and of every weight and bias."""
+    import torch
+    from rgp_amd.capi import Handle
+    from rgp_amd.mlp_encoder import MlpBackConstraint
+    H = Handle()
+    torch.manual_seed(3)
+    B = 3
+    up_len = N + Uw - 1 + 2 if Uw > 0 else 0                   # two leading rows outside every window
+    sp = dict(index=1, X_win=Xw, X_dim=Xd, U_win=Uw, U_dim=Ud, N=N, up_len=up_len)
+    enc = MlpBackConstraint([sp], B, X_variance=0.05, MLP_dims=list(dims_mid)).to(H.device)
+    enc.handle = H
+    with torch.no_grad():
+        enc.init_mean[0].normal_()
+        for p in enc.nets.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    controls = None
+    if Uw > 0:
+        controls = torch.randn(B, up_len, Ud, dtype=torch.float64, device=H.device, requires_grad=True)
+    w = torch.randn(B, Xw + N, Xd, dtype=torch.float64, device=H.device)
+    outs = []
+    for fn in (enc.forward, enc.forward_loop):
+        enc.zero_grad()
+        if controls is not None:
+            controls.grad = None
+        means, _ = fn(controls)
+        (means[0] * w).sum().backward()
+        H.sync()
+        outs.append((means[0].detach().clone(), [p.grad.clone() for p in enc.nets.parameters()], enc.init_mean[0].grad.clone(),
+                     None if controls is None else controls.grad.clone()))
+    (m1, gw1, gi1, gu1), (m2, gw2, gi2, gu2) = outs
+    tol = dict(rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), **tol)
+    np.testing.assert_allclose(gi1.cpu().numpy(), gi2.cpu().numpy(), **tol)
+    for a, b in zip(gw1, gw2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-11)
+    if gu1 is not None:
+        np.testing.assert_allclose(gu1.cpu().numpy(), gu2.cpu().numpy(), **tol)
+        assert float(gu1[:, :2].abs().max()) == 0.0            # rows above every window get no gradient
