@@ -588,13 +588,21 @@ class DeepAutoreg(object):
         ad['t_glob'] += 1
         if (allreduce is not None or lazy_elbo) and self._post_stream is None:
             self._post_stream = torch.cuda.ExternalStream(h.get_stream(1), device=self.device)
+        elbo_in_bucket = False
         for (lin, lout), L in zip(ios, self.layers):
             h.layer_step(lin, lout)
             a = min(v[0] for v in L.slices.values())
             b = max(v[1] for v in L.slices.values())
             if allreduce is not None:
                 with torch.cuda.stream(self._post_stream):
-                    allreduce(self.grad_array[a:b])
+                    if L is self.layers[-1] and b == self.elbo_slot:
+                        # the ELBO slot follows the last layer's parameters: it rides in that layer's all-reduce (every
+                        # layer's ELBO term has been written on this stream by now), one collective fewer per step
+                        self.grad_array[self.elbo_slot] = self._elbo_buf.sum()
+                        allreduce(self.grad_array[a:b + 1])
+                        elbo_in_bucket = True
+                    else:
+                        allreduce(self.grad_array[a:b])
             h.adam_step(self.opt_array[a:b], self.param_array[a:b], self.grad_array[a:b], ad['m'][a:b], ad['v'][a:b],
                         self.positive[a:b], lr, ad['t_glob'], post=True)
             h.layer_prepare(lin, PREPARE_CHAIN_ONLY)
@@ -605,12 +613,16 @@ class DeepAutoreg(object):
             # the per-layer ELBO terms are written on the side stream; summing them there keeps the main stream free of the
             # last layer's M x M algebra (the latent gradients it needs next come from main-stream kernels)
             with torch.cuda.stream(self._post_stream):
+                if elbo_in_bucket:
+                    return self.grad_array[self.elbo_slot].clone()
                 elbo = self._elbo_buf.sum()
                 if allreduce is not None:
                     allreduce(elbo)
                 self.grad_array[self.elbo_slot] = elbo
             return elbo
         h.join()
+        if elbo_in_bucket:
+            return self.grad_array[self.elbo_slot].clone()
         elbo = self._elbo_buf.sum()
         if allreduce is not None:
             allreduce(elbo)

@@ -34,7 +34,7 @@ def _globals0():
     return _model(Y, U).param_array[:_model(Y, U).n_global].clone()
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, lazy):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
@@ -49,18 +49,22 @@ def _worker(rank, world, port, out_path):
     allreduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
     elbos = []
     for k in range(STEPS):
-        e = m.svi_step(slice(0, b - a), lr=1e-2, allreduce=allreduce, qU_ratio=float(NTOT) / NTOT / world)
-        elbos.append(float(e.item()))
+        e = m.svi_step(slice(0, b - a), lr=1e-2, allreduce=allreduce, qU_ratio=float(NTOT) / NTOT / world, lazy_elbo=lazy)
+        elbos.append(e if lazy else float(e.item()))
     m.handle.sync()
+    if lazy:                       # as in bench.py: the ELBO scalars are read only after the final synchronisation
+        torch.cuda.synchronize()
+        elbos = [float(e.item()) for e in elbos]
     if rank == 0:
         np.savez(out_path, g=m.param_array[:m.n_global].cpu().numpy(), e=np.array(elbos))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_track_the_single_process_run(tmp_path):
+@pytest.mark.parametrize('lazy', [False, True])
+def test_two_ranks_track_the_single_process_run(tmp_path, lazy):
     out = str(tmp_path / 'dp.npz')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, lazy), nprocs=2, join=True)
     got = np.load(out)
     U, Y = make_data(NTOT, T, seed=0)
     m = _model(Y, U)
