@@ -738,7 +738,9 @@ psi1_svi_dz_kernel(const int64_t N, const int M, const double* __restrict__ Zc, 
   }
 }
 
-// pass R: lane = data row, the two waves of a workgroup take one half of the q columns each for the same 64 rows;
+// pass R: lane = data row, the NS (2 or 4) waves of a workgroup take one NS-th of the q columns each for the same 64 rows
+// (4 when there are fewer 64-row groups than SIMDs: the pass is then latency bound with one wave per SIMD, and the q split is
+// its only parallelism left);
 // z[m, half] and Cpsi1[m,:] are wave-uniform scalar operands.  Row-major [rows x cols] arrays are read and written
 // through 64 x 16 LDS tiles (global side: 16 lanes per row = 128 contiguous bytes; LDS side: one row per lane), because a
 // direct per-lane walk along a row touches 64 cache lines per load and moved 16x the bytes through L2 (586 us vs 50).
@@ -748,17 +750,18 @@ static __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <int QP, int DP, bool DY>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2)))
+template <int QP, int DP, bool DY, int NS>
+__global__ void __launch_bounds__(64 * NS) __attribute__((amdgpu_waves_per_eu(2)))
 psi1_svi_rows_kernel(const int64_t N, const int M, const int Q, const int D, const double* __restrict__ Zc,
                      const double* __restrict__ lam, const double* __restrict__ Xmu, const double* __restrict__ e1,
                      const double* __restrict__ Lp, const double* __restrict__ P, const double* __restrict__ Cpsi1,
                      const double* __restrict__ Ym, const double* __restrict__ noise, double* __restrict__ gmu,
                      double* __restrict__ gS, double* __restrict__ dYm, double* __restrict__ dlam_part,
                      double* __restrict__ lsum_part) {
-  constexpr int QH = QP / 2;
+  constexpr int QH = QP / NS;
+  constexpr int NTH = 64 * NS;
   // sweep: two 64 x 16 tiles (Lp chunk, P chunk); epilogue: per wave one 64 x (16 + 16) tile of s1 | s2 columns plus s0
-  __shared__ double shbuf[2 * (64 * 2 * P1_RT) + 2 * 64];
+  __shared__ double shbuf[NS * (64 * 2 * P1_RT) + NS * 64];
   double* const tl0 = shbuf;
   double* const tl1 = shbuf + 64 * P1_RT;
   __shared__ double dl_s[QP];
@@ -779,12 +782,13 @@ psi1_svi_rows_kernel(const int64_t N, const int M, const int Q, const int D, con
 #pragma unroll
     for (int d = 0; d < DP; ++d) dy[d] = 0.0;
     for (int m0 = 0; m0 < M; m0 += 16) {
-      double lv[8], pv[8];
-      bool vm[8];
+      constexpr int NLD = 1024 / NTH;                 // tile elements per thread
+      double lv[NLD], pv[NLD];
+      bool vm[NLD];
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = t + 128 * k, row = i >> 4, col = i & 15;
+      for (int k = 0; k < NLD; ++k) {
+        const int i = t + NTH * k, row = i >> 4, col = i & 15;
         const bool valid = (n0 + row < N) && (m0 + col < M);
         const int64_t src = (valid ? n0 + row : N - 1) * M + (valid ? m0 + col : 0);     // clamped: no branch around the load
         lv[k] = Lp[src];
@@ -792,8 +796,8 @@ psi1_svi_rows_kernel(const int64_t N, const int M, const int Q, const int D, con
         vm[k] = valid;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = t + 128 * k, row = i >> 4, col = i & 15;
+      for (int k = 0; k < NLD; ++k) {
+        const int i = t + NTH * k, row = i >> 4, col = i & 15;
         tl0[row * P1_RT + col] = vm[k] ? lv[k] : 0.0;
         if (DY) tl1[row * P1_RT + col] = vm[k] ? pv[k] : 0.0;
       }
@@ -823,7 +827,7 @@ psi1_svi_rows_kernel(const int64_t N, const int M, const int Q, const int D, con
     // (16 lanes per row): mu, e are read and gmu, gS written as 128-byte row segments.
     __syncthreads();                                  // both waves are done with the Lp / P tiles: the buffer is reused
     double* st = shbuf + (size_t)half * (64 * 2 * P1_RT);
-    double* s0t = shbuf + 2 * (64 * 2 * P1_RT) + half * 64;
+    double* s0t = shbuf + NS * (64 * 2 * P1_RT) + half * 64;
     s0t[lane] = s0;
 #pragma unroll
     for (int c0 = 0; c0 < QH; c0 += 16) {
@@ -898,11 +902,18 @@ static void psi1_svi_dispatch(hipStream_t s, int64_t N, int M, int Q, int D, con
     hipLaunchKernelGGL((psi1_svi_fwd_kernel<QP, DP>), dim3(nblk), dim3(256), 0, s, N, M, D, zt.Zc, rt.e1, rt.em, rt.g1, Ym,
                        Cpsi1, dYm ? P : nullptr, Lp, psi1Y_part);
   const int rb = psi1_svi_rows_blocks(N);
-  if (dYm)
-    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, DP, true>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+  if ((N + 63) / 64 < 640) {                // far fewer 64-row groups than SIMDs (1024): four q quarters per group (+1.2 % per step at 255 groups)
+    if (dYm)
+      hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, DP, true, 4>), dim3(rb), dim3(256), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+                         rt.e1, Lp, P, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
+    else
+      hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false, 4>), dim3(rb), dim3(256), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+                         rt.e1, Lp, Lp, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
+  } else if (dYm)
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, DP, true, 2>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
                        rt.e1, Lp, P, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
   else
-    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false, 2>), dim3(rb), dim3(128), 0, s, N, M, Q, D, zt.Zc, zt.lam, rt.Xmu,
                        rt.e1, Lp, Lp, Cpsi1, Ym, noise, gmu, gS, dYm, dlam_part, lsum_part);
   hipLaunchKernelGGL((psi1_svi_dz_kernel<QP>), dim3(nblk), dim3(256), 0, s, N, M, zt.Zc, rt.e1, rt.em, Lp, dz_part);
 }
