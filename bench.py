@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-update', action='store_true', help='debug: skip the Adam update (kernel ablation runs); INVALID as a benchmark')
+    ap.add_argument('--no-prefetch', action='store_true', help='debug: do not prepare the next minibatch during the running step')
     ap.add_argument('--n-total', type=int, default=256, help='sequences in the dataset (config 4: 256)')
     ap.add_argument('--T', type=int, default=4096)
     ap.add_argument('--minibatch', type=int, default=32)
@@ -96,10 +97,12 @@ def main():
     n_mb = n_loc // mb_loc
     def step(k):
         j = k % n_mb
+        j2 = (k + 1) % n_mb            # the data streamer's next minibatch: its row terms are prepared while this step runs
+        nxt = slice(j2 * mb_loc, (j2 + 1) * mb_loc) if (n_mb > 1 and not a.no_update and not a.no_prefetch) else None
         # lazy_elbo: the ELBO scalar is produced on the library's side stream; it is read only after the final synchronisation
         return m.svi_step(slice(j * mb_loc, (j + 1) * mb_loc), lr=a.lr, allreduce=allreduce,
                           qU_ratio=float(mb) / n_total / world if world > 1 else None, update=not a.no_update,
-                          lazy_elbo=not a.no_update)
+                          lazy_elbo=not a.no_update, next_seqs=nxt)
 
     for k in range(a.warmup):
         step(k)

@@ -131,6 +131,10 @@ rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_
  * rgp_discard_prepared drops prepared layers that will not be stepped (parameters changed by other means). */
 #define RGP_PREPARE_CHAIN_ONLY 1
 #define RGP_PREPARE_ROWS_ONLY 2
+/* with RGP_PREPARE_ROWS_ONLY: the sequences of this minibatch are not touched by any work in flight (e.g. the NEXT minibatch of
+ * a data streamer, disjoint from the running one), so the row terms need not wait for the main stream's position; they are
+ * computed behind the layer's chain-only prepare while the running step still occupies the main stream. */
+#define RGP_PREPARE_ROWS_EARLY 4
 rgp_status rgp_adam_step_post(rgp_handle h, int64_t n, double* x, double* p, const double* g, double* m, double* v,
                               const uint8_t* positive, double lr, double beta1, double beta2, double eps, int64_t step);
 rgp_status rgp_discard_prepared(rgp_handle h);

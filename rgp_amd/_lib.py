@@ -76,7 +76,7 @@ SYMBOLS = {
     'rgp_mlp_scan_forward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
     'rgp_mlp_scan_backward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
 }
-PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY = 1, 2          # rgp_layer_in.reserved for rgp_layer_prepare
+PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY, PREPARE_ROWS_EARLY = 1, 2, 4          # rgp_layer_in.reserved for rgp_layer_prepare
 
 _lib = None
 

@@ -1000,6 +1000,10 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
       RGP_HIP_CHECK(h, hipEventRecord(h->ev_post_pos, h->side_post));
       RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_post_pos, 0));
       if (h->slot_main_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_slot_main[slot], 0));
+    } else if (mode == 2 && (in->reserved & RGP_PREPARE_ROWS_EARLY)) {
+      // the caller vouches that nothing in flight writes these sequences' signals: only the slot's previous main-stream user
+      // has to be finished (its side-stream users are covered by the chain-only prepare, whose prep_z event is waited for below)
+      if (h->slot_main_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_slot_main[slot], 0));
     } else {
       // parameters and signals are written by main-stream work (the previous step's update), and the slot's previous
       // user on the main stream must be finished too

@@ -377,11 +377,17 @@ class DeepAutoreg(object):
         if getattr(self, '_chain_ready', False):
             self.handle.discard_prepared()
             self._chain_ready = False
+        self._rows_key = None
 
     def _build_ios(self, seqs, qU_ratio):
         """rgp_layer_in / rgp_layer_out of every layer (top first) for the sequences ``seqs``."""
         n_batch = None
+        hist = getattr(self, '_keep_hist', None)            # tables of the last few calls stay alive: kernels of pipelined steps
+        if hist is None:                                    # (and of a prefetched minibatch) may still read them
+            hist = self._keep_hist = []
         self._keep = []
+        hist.append(self._keep)
+        del hist[:-6]
         ios = []
         for k, L in enumerate(self.layers):
             dev, n_seq, N, own_rows, up_rows = self._seq_tables(L, seqs)
@@ -526,24 +532,30 @@ class DeepAutoreg(object):
         self._adam = dict(m=torch.zeros_like(self.param_array), v=torch.zeros_like(self.param_array),
                           t_glob=0, t_loc=np.zeros(self.nSeq, dtype=np.int64))
 
-    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True, lazy_elbo=False):
+    def svi_step(self, seqs, lr=1e-2, allreduce=None, qU_ratio=None, update=True, lazy_elbo=False, next_seqs=None):
         """One SVI step on the sequences ``seqs`` (slice of contiguous indices or index list): ELBO + gradients,
         optional all-reduce of the global bucket (data-parallel), one Adam update of the global parameters and of the
         touched sequences' latent parameters.  Returns the device ELBO scalar (pre-update).
 
         lazy_elbo=True (pipelined steps only): the ELBO is summed on the library's side stream and the main stream does not
         wait for the last layer's M x M algebra, so the next step's row work starts earlier; the returned tensor may only be
-        read after ``handle.join()`` / a device synchronisation."""
+        read after ``handle.join()`` / a device synchronisation.
+
+        next_seqs (pipelined steps only): the minibatch of the FOLLOWING step when the data streamer already knows it.  If it
+        shares no sequence with ``seqs`` its row terms are computed while this step still runs (RGP_PREPARE_ROWS_EARLY), so the
+        next step does not start with the row preparation of its first layer; a hint that turns out wrong only costs the
+        prefetch (the prepared layers are discarded)."""
         if self._adam is None:
             self._init_adam()
         ad, h = self._adam, self.handle
         pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate
         if pipelined:
             try:
-                elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo)
+                elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo, next_seqs)
             except Exception:
                 h.discard_prepared()
                 self._chain_ready = False
+                self._rows_key = None
                 raise
         else:
             elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
@@ -572,23 +584,45 @@ class DeepAutoreg(object):
                             self.positive[sl], lr, t)
         return elbo
 
-    def _svi_step_pipelined(self, seqs, lr, allreduce, qU_ratio, lazy_elbo=False):
+    @staticmethod
+    def _seq_key(seqs, n):
+        if seqs is None:
+            return tuple(range(n))
+        if isinstance(seqs, slice):
+            return tuple(range(*seqs.indices(n)))
+        return tuple(int(x) for x in seqs)
+
+    def _svi_step_pipelined(self, seqs, lr, allreduce, qU_ratio, lazy_elbo=False, next_seqs=None):
         """ELBO + gradients + update of the GLOBAL parameters, layer by layer: as soon as a layer's gradients exist (library
         side stream) they are all-reduced and applied there, and the M x M chain of the NEXT step is started for that layer
         while the main stream is still busy with the psi passes of the layers below (include/rgp_hip.h, pipelining
         section).  Same arithmetic as evaluate + one Adam step; only the order of independent work changes."""
-        from ._lib import PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY
+        from ._lib import PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY, PREPARE_ROWS_EARLY
         ad, h = self._adam, self.handle
+        key = self._seq_key(seqs, self.nSeq)
+        rows_key = getattr(self, '_rows_key', None)
+        if rows_key is not None and rows_key != (key, qU_ratio):
+            self._flush_pipeline()                      # the prefetched rows belong to another minibatch
         ios, n_batch = self._build_ios(seqs, qU_ratio)
         n_prev = getattr(self, '_chain_n', None)
         if self._chain_ready and n_prev is not None and any(lin.N > n for (lin, _), n in zip(ios, n_prev)):
             self._flush_pipeline()                      # larger minibatch than the early chains were sized for
-        for lin, _ in ios:
-            h.layer_prepare(lin, PREPARE_ROWS_ONLY if self._chain_ready else 0)
+        if getattr(self, '_rows_key', None) is None:
+            for lin, _ in ios:
+                h.layer_prepare(lin, PREPARE_ROWS_ONLY if self._chain_ready else 0)
+        self._rows_key = None
+        ios_next = None
+        if next_seqs is not None:
+            nkey = self._seq_key(next_seqs, self.nSeq)
+            if not set(nkey) & set(key):
+                ios_next, _ = self._build_ios(next_seqs, qU_ratio)
+                if any(ln.N > lc.N for (ln, _), (lc, _) in zip(ios_next, ios)):
+                    ios_next = None                     # the chain-only prepare below is sized for this step's minibatch
         ad['t_glob'] += 1
         if (allreduce is not None or lazy_elbo) and self._post_stream is None:
             self._post_stream = torch.cuda.ExternalStream(h.get_stream(1), device=self.device)
         elbo_in_bucket = False
+        done = []
         for (lin, lout), L in zip(ios, self.layers):
             h.layer_step(lin, lout)
             a = min(v[0] for v in L.slices.values())
@@ -606,6 +640,11 @@ class DeepAutoreg(object):
             h.adam_step(self.opt_array[a:b], self.param_array[a:b], self.grad_array[a:b], ad['m'][a:b], ad['v'][a:b],
                         self.positive[a:b], lr, ad['t_glob'], post=True)
             h.layer_prepare(lin, PREPARE_CHAIN_ONLY)
+            if ios_next is not None:                    # rows of the next minibatch, behind this layer's new chain
+                h.layer_prepare(ios_next[len(done)][0], PREPARE_ROWS_ONLY | PREPARE_ROWS_EARLY)
+            done.append(L)
+        if ios_next is not None:
+            self._rows_key = (nkey, qU_ratio)
         self._chain_ready = True
         self._chain_n = [lin.N for lin, _ in ios]
         self._last_n_batch = n_batch

@@ -405,3 +405,35 @@ def test_pipelined_svi_steps_equal_plain_steps():
     assert abs(float(ea_l[-1].item()) - eb_l[-1]) <= 1e-11 * abs(eb_l[-1])
     a.handle.sync(); b.handle.sync()
     assert float((a.param_array - b.param_array).abs().max()) <= 1e-11 * float(b.param_array.abs().max())
+
+
+def test_prefetched_next_minibatch_equals_plain_steps():
+    """svi_step(next_seqs=...) prepares the following minibatch's row terms while the running step still owns the main stream
+    (RGP_PREPARE_ROWS_EARLY); results must not change -- including a wrong hint, an overlapping hint and a hint followed by
+    evaluate()."""
+    import torch
+    _, a = build_pair(n_seq=6, T=40, M=6, seed=7, n_total=6)
+    _, b = build_pair(n_seq=6, T=40, M=6, seed=7, n_total=6)
+    b.pipeline = False
+    mbs = [slice(0, 2), slice(2, 4), slice(4, 6)]
+    ea, eb = [], []
+    for k in range(7):
+        ea.append(a.svi_step(mbs[k % 3], lr=2e-2, lazy_elbo=True, next_seqs=mbs[(k + 1) % 3]))
+        eb.append(float(b.svi_step(mbs[k % 3], lr=2e-2).item()))
+    # wrong hint (the step that follows uses other sequences), then an overlapping hint (ignored), then a list hint
+    ea.append(a.svi_step(mbs[1], lr=2e-2, lazy_elbo=True, next_seqs=mbs[0]))
+    eb.append(float(b.svi_step(mbs[1], lr=2e-2).item()))
+    ea.append(a.svi_step(mbs[2], lr=2e-2, lazy_elbo=True, next_seqs=slice(3, 5)))
+    eb.append(float(b.svi_step(mbs[2], lr=2e-2).item()))
+    ea.append(a.svi_step([0, 1], lr=2e-2, lazy_elbo=True, next_seqs=[4, 5]))
+    eb.append(float(b.svi_step([0, 1], lr=2e-2).item()))
+    ea.append(a.svi_step([4, 5], lr=2e-2, lazy_elbo=True, next_seqs=[2, 3]))
+    eb.append(float(b.svi_step([4, 5], lr=2e-2).item()))
+    a.handle.sync(); b.handle.sync()
+    torch.cuda.synchronize()
+    for k, (x, y) in enumerate(zip(ea, eb)):
+        assert abs(float(x.item()) - y) <= 1e-11 * abs(y), (k, float(x.item()), y)
+    e1 = float(a.evaluate().item()); e2 = float(b.evaluate().item())        # drops the prefetched rows and chains
+    a.handle.sync(); b.handle.sync()
+    assert abs(e1 - e2) <= 1e-11 * abs(e2)
+    assert float((a.param_array - b.param_array).abs().max()) <= 1e-11 * float(b.param_array.abs().max())
