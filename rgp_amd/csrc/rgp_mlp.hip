@@ -28,8 +28,12 @@ struct MlpDev {
   int ring_off, uring_off, v0_off, v1_off;                 // LDS offsets (doubles)
 };
 
+// sum over aligned groups of P = 1, 2, 4 or 8 adjacent lanes (P is uniform over the workgroup): DPP lane exchanges instead of
+// __shfl_xor, which compiles to ds_bpermute -- an LDS round trip per exchange on the critical path of every layer of every step
 static __device__ __forceinline__ double group_sum(double v, int P) {
-  for (int m = P >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  if (P >= 2) v += dpp_f64<0xB1>(v);            // quad_perm [1,0,3,2]
+  if (P >= 4) v += dpp_f64<0x4E>(v);            // quad_perm [2,3,0,1]
+  if (P >= 8) v += dpp_f64<0x141>(v);           // row_half_mirror
   return v;
 }
 
