@@ -620,7 +620,8 @@ class DeepAutoreg(object):
                     ios_next = None                     # the chain-only prepare below is sized for this step's minibatch
         ad['t_glob'] += 1
         if (allreduce is not None or lazy_elbo) and self._post_stream is None:
-            self._post_stream = torch.cuda.ExternalStream(h.get_stream(1), device=self.device)
+            sp = h.get_stream(1)            # NULL = the default stream (RGP_NO_OVERLAP debugging runs on a handle made there)
+            self._post_stream = torch.cuda.ExternalStream(sp, device=self.device) if sp else torch.cuda.default_stream(self.device)
         elbo_in_bucket = False
         done = []
         for (lin, lout), L in zip(ios, self.layers):
