@@ -10,6 +10,7 @@ struct SviChain {
   // workspace (device, carved by svi_chain_carve)
   double *Linv, *S, *LsInv, *B, *T1, *T2, *T3, *mA, *Kinv, *Gv;
   double *dLdpsi2, *dKmm;                               // results consumed by the psi backward / K backward
+  double *dLs_sym = nullptr;                            // optional (layer workspace): 1/2 (dL_dpsi2 + dL_dpsi2^T) for the psi2 pass
   double *Sinv, *Wi;                                    // S^-1 and woodbury_inv, produced by stage 1c for stage 2
   double *gmu, *Kinv_mu, *Cpsi1, *Ybt, *gqm;
   double *scal, *bound, *dthetaL;

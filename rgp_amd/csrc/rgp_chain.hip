@@ -441,6 +441,8 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_pre_b_kernel(SviChain c)
   __syncthreads();
   wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
   wg_gemm<true, false>(M, M, M, 0.5 * beta, c.Linv, M, c.T2, M, 0.0, c.dLdpsi2, M, lds);
+  if (c.dLs_sym)
+    for (int i = t; i < M * M; i += blockDim.x) c.dLs_sym[i] = 0.5 * (c.dLdpsi2[i] + c.dLdpsi2[(i % M) * M + i / M]);
   const double trB = block_sum((t < M) ? c.B[t * M + t] : 0.0, scratch);
   if (t == 0) c.scal[2] = trB;      // D ||E||^2 + ||gmu||^2
 }

@@ -1021,6 +1021,7 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
       h->prepz_recorded[slot] = true;
     }
     c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
+    c.dLs_sym = L.dLs;                               // the psi2 pass reads the symmetrised dL/dpsi2
     if (h->overlap && s != s_pre) {
       RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, s));
       RGP_HIP_CHECK(h, hipStreamWaitEvent(s_pre, h->ev_prep, 0));
@@ -1137,17 +1138,15 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv; c.status = h->status;
 
   // psi1 side
+  bool psi1_fast = false;
   if (psi1_svi_supported(D)) {
     if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_a[slot], 0));  // Cpsi1 comes from the chain's first kernel
     GAP_MARK(1, false);
     launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
                     in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
-    const int rb = psi1_svi_rows_blocks(N);
-    const ReduceSeg segs[4] = {{L.psi1Y_part, L.psi1Y, L.nblk1, (int64_t)D * M, (int64_t)D * M},
-                               {L.dlam1_part, L.dlam1, rb, QP, QP},
-                               {L.lsum1_part, L.lsum1, rb, 1, 1},
-                               {L.dz1_part, L.dz1, L.nblk1, (int64_t)M * QP, (int64_t)M * QP}};
-    launch_reduce_batch(s, 4, segs);
+    // the partial sums of the three passes are reduced on the side stream together with the psi2 partials (below): nothing
+    // on the main stream reads them
+    psi1_fast = true;
   } else {
     launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
     if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));
@@ -1165,10 +1164,10 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
   }
 
+  Psi2Plan pl2;
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_b[slot], 0));    // dL_dpsi2 comes from the chain's second kernel
-  GAP_MARK(2, false);
-  hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
+  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_b[slot], 0));    // dL_dpsi2 (symmetrised into L.dLs) comes
+  GAP_MARK(2, false);                                                               // from the chain's second kernel
   {
     Psi2Out o{};
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
@@ -1178,13 +1177,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid);
     prof_end(h);
     if (st) return st;
-    const int tri = M * (M + 1) / 2;
-    const ReduceSeg segs[4] = {{L.p2_part, L.p2_tri, pl.n_p2, tri, tri},
-                               {L.dz2_part, L.dz2, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM},
-                               {L.dlam2_part, L.dlam2, pl.n_dl, QP, QP},
-                               {L.wsum2_part, L.wsum2, pl.n_dl, 1, 1}};
-    launch_reduce_batch(s, 4, segs);
-    launch_unpack_tri(s, M, L.p2_tri, L.psi2);
+    pl2 = pl;
   }
 
   // latent gradients (main stream; they need only the row gradients and dL/dY)
@@ -1212,6 +1205,37 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre[slot], 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_yry[slot], 0));
+  }
+  {
+    // fixed-order sums of the per-workgroup partials of the psi passes: consumed only by the algebra and the gradient
+    // finalisation below.  Short passes (their grid leaves CUs free): on the side stream, not in front of the next layer's psi
+    // passes (+2.4 % per step at 4 sequences per rank).  Long passes fill the chip, the side-stream reductions would take CUs
+    // from the next pass (-0.2 % at 32 sequences), so they stay on the main stream there.
+    const bool red_side = h->overlap && pl2.grid < h->num_cu;
+    hipStream_t s_red = red_side ? s_post : s;
+    const int tri = M * (M + 1) / 2;
+    const int rb = psi1_svi_rows_blocks(N);
+    ReduceSeg segs[8];
+    int ns = 0;
+    if (psi1_fast) {
+      segs[ns++] = {L.psi1Y_part, L.psi1Y, L.nblk1, (int64_t)D * M, (int64_t)D * M};
+      segs[ns++] = {L.dlam1_part, L.dlam1, rb, QP, QP};
+      segs[ns++] = {L.lsum1_part, L.lsum1, rb, 1, 1};
+      segs[ns++] = {L.dz1_part, L.dz1, L.nblk1, (int64_t)M * QP, (int64_t)M * QP};
+      launch_reduce_batch(s_red, ns, segs);
+      ns = 0;
+    }
+    segs[ns++] = {L.p2_part, L.p2_tri, pl2.n_p2, tri, tri};
+    segs[ns++] = {L.dz2_part, L.dz2, pl2.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM};
+    segs[ns++] = {L.dlam2_part, L.dlam2, pl2.n_dl, QP, QP};
+    segs[ns++] = {L.wsum2_part, L.wsum2, pl2.n_dl, 1, 1};
+    launch_reduce_batch(s_red, ns, segs);
+    launch_unpack_tri(s_red, M, L.p2_tri, L.psi2);
+    if (h->overlap && !red_side) {                  // the side stream needs the reduced statistics: re-issue its wait
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
+    }
   }
   if ((st = launch_svi_chain_post(h, c, s_post))) return st;
   {
