@@ -1099,6 +1099,15 @@ extern "C" rgp_status rgp_get_stream(rgp_handle h, int which, void** stream) {
   return RGP_OK;
 }
 
+// Make `s` wait for `ev` unless the recorded work has already finished: a wait on a completed event is still a packet the
+// stream's queue has to process (~4 us), and with pipelined steps the side-stream work a layer step depends on is usually long
+// done when the step is issued.
+static hipError_t wait_if_pending(hipStream_t s, hipEvent_t ev) {
+  if (hipEventQuery(ev) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();                       // hipErrorNotReady is sticky for hipGetLastError
+  return hipStreamWaitEvent(s, ev, 0);
+}
+
 extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
   if (!h || !in || !out) return RGP_ERR_BAD_ARG;
   if (in->mode == RGP_MODE_VARDTC) return vardtc_layer_step(h, in, out);
@@ -1131,7 +1140,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   // the window tables and row terms were produced by svi_prepare_slot (side_rows stream)
   WindowSpec w = svi_window_spec(in, L);
   GAP_MARK(0, true);
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_rows[slot], 0));
+  if (h->overlap) RGP_HIP_CHECK(h, wait_if_pending(s, h->ev_rows[slot]));
 
   c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a;
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
@@ -1140,7 +1149,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   // psi1 side
   bool psi1_fast = false;
   if (psi1_svi_supported(D)) {
-    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_a[slot], 0));  // Cpsi1 comes from the chain's first kernel
+    if (h->overlap) RGP_HIP_CHECK(h, wait_if_pending(s, h->ev_pre_a[slot]));  // Cpsi1 comes from the chain's first kernel
     GAP_MARK(1, false);
     launch_psi1_svi(s, N, M, Q, D, L.zt, L.rt, L.Ym, c.Cpsi1, in->noise, L.psi1, L.Lp, L.psi1Y_part, L.gmu, L.gS,
                     in->y_uncertain ? L.dYm : nullptr, L.dlam1_part, L.lsum1_part, L.dz1_part, L.nblk1);
@@ -1166,7 +1175,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   Psi2Plan pl2;
   // psi2: forward sum and backward in one pass (dL_dpsi2 does not depend on the statistics in the SVI bound)
-  if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre_b[slot], 0));    // dL_dpsi2 (symmetrised into L.dLs) comes
+  if (h->overlap) RGP_HIP_CHECK(h, wait_if_pending(s, h->ev_pre_b[slot]));    // dL_dpsi2 (symmetrised into L.dLs) comes
   GAP_MARK(2, false);                                                               // from the chain's second kernel
   {
     Psi2Out o{};
@@ -1199,10 +1208,9 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   GAP_MARK(3, false);
   // data-dependent algebra + kernel-hyperparameter gradients on the side stream: overlaps the next layer's psi passes
   if (h->overlap) {
-    RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));
-    h->slot_main_recorded[slot] = true;
-    RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
-    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));        // one event for both uses: every record is a packet the
+    h->slot_main_recorded[slot] = true;                                // main stream's queue has to process (~4 us each)
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_slot_main[slot], 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_pre[slot], 0));
     RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_yry[slot], 0));
   }
@@ -1233,8 +1241,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     launch_unpack_tri(s_red, M, L.p2_tri, L.psi2);
     if (h->overlap && !red_side) {                  // the side stream needs the reduced statistics: re-issue its wait
       RGP_HIP_CHECK(h, hipEventRecord(h->ev_slot_main[slot], s));
-      RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
-      RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_stats, 0));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(s_post, h->ev_slot_main[slot], 0));
     }
   }
   if ((st = launch_svi_chain_post(h, c, s_post))) return st;
