@@ -1217,9 +1217,9 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   {
     // fixed-order sums of the per-workgroup partials of the psi passes: consumed only by the algebra and the gradient
     // finalisation below.  Short passes (their grid leaves CUs free): on the side stream, not in front of the next layer's psi
-    // passes (+2.4 % per step at 4 sequences per rank).  Long passes fill the chip, the side-stream reductions would take CUs
-    // from the next pass (-0.2 % at 32 sequences), so they stay on the main stream there.
-    const bool red_side = h->overlap && pl2.grid < h->num_cu;
+    // passes (+2.4 % per step at 4 sequences per rank).  Longer passes leave few or no CUs free, the side-stream reductions would
+    // take CUs from the next pass (-0.2 % at 32 sequences), so they stay on the main stream there.
+    const bool red_side = h->overlap && pl2.grid <= h->num_cu - 16;      // (248 workgroups, 16 sequences per rank: -1.4 % on the side)
     hipStream_t s_red = red_side ? s_post : s;
     const int tri = M * (M + 1) / 2;
     const int rb = psi1_svi_rows_blocks(N);
