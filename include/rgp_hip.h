@@ -221,6 +221,28 @@ typedef struct rgp_mlp_scan {
 rgp_status rgp_mlp_scan_forward(rgp_handle h, const rgp_mlp_scan* a);
 rgp_status rgp_mlp_scan_backward(rgp_handle h, const rgp_mlp_scan* a);
 
+/* ---- GRU recurrence of the sequence-encoder back-constraint as a per-sequence persistent scan ----------------------
+ * Replaces the time loop inside PyTorch's nn.GRU as used by autoreg/rnn_encoder.py:21-83 (one layer, h_0 = 0, gate order
+ * r, z, n as in PyTorch):  gh = W_hh h + b_hh;  r = sigmoid(gi_r + gh_r);  z = sigmoid(gi_z + gh_z);
+ * n = tanh(gi_n + r gh_n);  h' = (1 - z) n + z h.   The input projections gi[t] = W_ih x_t + b_ih are the caller's GEMM.
+ * Layouts (PyTorch's (seq_len, batch, feature)): gi [T][B][3H]; W_hh [3H][H]; b_hh [3H]; hseq [T][B][H];
+ * gates [T][B][4H] = r | z | n | gh_n (forward output, backward input).
+ * Backward: g_out [T][B][H] = dL/dh_t -> dgi [T][B][3H] = dL/d gi_t and dgh [T][B][3H] = dL/d gh_t;
+ * dW_hh = sum_t dgh_t h_{t-1}^T, db_hh = sum_t dgh_t (GEMMs on the caller's side).  H <= 80 (W_hh lives in LDS). */
+typedef struct rgp_gru_scan {
+  int32_t T, B, H, reserved;
+  const double* gi;
+  const double* W_hh;
+  const double* b_hh;
+  double* hseq;
+  double* gates;
+  const double* g_out;
+  double* dgi;
+  double* dgh;
+} rgp_gru_scan;
+rgp_status rgp_gru_scan_forward(rgp_handle h, const rgp_gru_scan* a);
+rgp_status rgp_gru_scan_backward(rgp_handle h, const rgp_gru_scan* a);
+
 /* ---- optimiser step on device (the outer SVI loop's Adam; positive parameters live in softplus space) -------- */
 /* x, m, v: n doubles of optimiser-space parameter and Adam moments; g: gradient w.r.t. the CONSTRAINED value p;
  * positive[i] != 0 -> p = softplus(x) and the chain factor 1-exp(-p) is applied (paramz Logexp).  The new constrained

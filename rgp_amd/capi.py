@@ -205,5 +205,31 @@ def mlp_scan_backward(handle, spec, dims, up, Ws, bs, acts, g_mean, want_g_up):
     return g_init, g_up, deltas
 
 
+def gru_scan_forward(handle, gi, W_hh, b_hh):
+    """rgp_gru_scan_forward: gi (T, B, 3H) -> (hseq (T, B, H), gates (T, B, 4H))."""
+    _chk64(gi, W_hh, b_hh)
+    T, B, H3 = gi.shape
+    H = H3 // 3
+    hseq, gates = handle.new(T, B, H), handle.new(T, B, 4 * H)
+    a = _lib.GruScan()
+    a.T, a.B, a.H = T, B, H
+    a.gi, a.W_hh, a.b_hh, a.hseq, a.gates = gi.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr(), gates.data_ptr()
+    handle._check(handle.lib.rgp_gru_scan_forward(handle.h, C.byref(a)))
+    return hseq, gates
+
+
+def gru_scan_backward(handle, W_hh, b_hh, hseq, gates, g_out):
+    """rgp_gru_scan_backward: g_out (T, B, H) -> (dgi, dgh), both (T, B, 3H)."""
+    _chk64(g_out)
+    T, B, H = hseq.shape
+    dgi, dgh = handle.new(T, B, 3 * H), handle.new(T, B, 3 * H)
+    a = _lib.GruScan()
+    a.T, a.B, a.H = T, B, H
+    a.W_hh, a.b_hh, a.hseq, a.gates = W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr(), gates.data_ptr()
+    a.g_out, a.dgi, a.dgh = g_out.data_ptr(), dgi.data_ptr(), dgh.data_ptr()
+    handle._check(handle.lib.rgp_gru_scan_backward(handle.h, C.byref(a)))
+    return dgi, dgh
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()

@@ -756,6 +756,8 @@ class DeepAutoreg_rnn(DeepAutoreg):
         in_dims[0] += (Us[0].shape[1] if Us is not None else 0)              # encode_include_input (model.py:409-412)
         hid = rnn_hidden_dims[0] if rnn_hidden_dims is not None else 10
         self.encoder = SeqEncoder(in_dims, self.nDims[1:], hid, rnn_type, rnn_bidirectional).to(self.device)
+        for lay in self.encoder.layers:                                      # GRU time loops run as device scans
+            lay.handle = self.handle
         raw = np.stack([np.hstack([y, u]) if Us is not None else y for y, u in zip(Ys, Us or Ys)], axis=1)
         self.enc_input = torch.as_tensor(raw, dtype=torch.float64, device=self.device)       # (T, n_seq, D_y + D_u)
         # flat offsets of (t, s, h) of hidden layer i inside the means / vars regions

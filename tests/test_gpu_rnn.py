@@ -101,3 +101,35 @@ def test_svi_steps_improve_the_bound():
     e1 = float(m.evaluate().item())
     m.handle.sync()
     assert np.isfinite(e1) and e1 > e0, (e0, e1)
+
+
+@pytest.mark.parametrize('T,B,Din,H,bi', [(9, 3, 5, 4, False), (40, 2, 7, 20, True), (25, 1, 3, 33, False), (17, 4, 2, 80, False)])
+def test_gru_scan_matches_torch_gru(T, B, Din, H, bi):
+    """rgp_gru_scan_forward/_backward (device scan of the GRU time loop) against torch's own nn.GRU on the same module:
+    outputs, and the gradients of every weight, bias and of the input."""
+    import torch
+    from rgp_amd.capi import Handle
+    from rgp_amd.rnn_encoder import MeanVarRNN
+    Hd = Handle()
+    torch.manual_seed(5)
+    lay = MeanVarRNN(Din, 3, H, 'gru', bi).double().to(Hd.device)
+    lay.handle = Hd
+    x = torch.randn(T, B, Din, dtype=torch.float64, device=Hd.device, requires_grad=True)
+    wm = torch.randn(T, B, 3, dtype=torch.float64, device=Hd.device)
+    wv = torch.randn(T, B, 3, dtype=torch.float64, device=Hd.device)
+    res = []
+    for scan in (True, False):
+        lay.use_scan = scan
+        lay.zero_grad()
+        x.grad = None
+        mean, var = lay(x)
+        ((mean * wm).sum() + (var * wv).sum()).backward()
+        Hd.sync()
+        res.append((mean.detach().clone(), var.detach().clone(), x.grad.clone(), [p.grad.clone() for p in lay.parameters()]))
+    (m1, v1, gx1, gp1), (m2, v2, gx2, gp2) = res
+    tol = dict(rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), **tol)
+    np.testing.assert_allclose(v1.cpu().numpy(), v2.cpu().numpy(), **tol)
+    np.testing.assert_allclose(gx1.cpu().numpy(), gx2.cpu().numpy(), **tol)
+    for a, b in zip(gp1, gp2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, atol=1e-11)
