@@ -221,16 +221,23 @@ typedef struct rgp_mlp_scan {
 rgp_status rgp_mlp_scan_forward(rgp_handle h, const rgp_mlp_scan* a);
 rgp_status rgp_mlp_scan_backward(rgp_handle h, const rgp_mlp_scan* a);
 
-/* ---- GRU recurrence of the sequence-encoder back-constraint as a per-sequence persistent scan ----------------------
- * Replaces the time loop inside PyTorch's nn.GRU as used by autoreg/rnn_encoder.py:21-83 (one layer, h_0 = 0, gate order
- * r, z, n as in PyTorch):  gh = W_hh h + b_hh;  r = sigmoid(gi_r + gh_r);  z = sigmoid(gi_z + gh_z);
- * n = tanh(gi_n + r gh_n);  h' = (1 - z) n + z h.   The input projections gi[t] = W_ih x_t + b_ih are the caller's GEMM.
- * Layouts (PyTorch's (seq_len, batch, feature)): gi [T][B][3H]; W_hh [3H][H]; b_hh [3H]; hseq [T][B][H];
- * gates [T][B][4H] = r | z | n | gh_n (forward output, backward input).
- * Backward: g_out [T][B][H] = dL/dh_t -> dgi [T][B][3H] = dL/d gi_t and dgh [T][B][3H] = dL/d gh_t;
- * dW_hh = sum_t dgh_t h_{t-1}^T, db_hh = sum_t dgh_t (GEMMs on the caller's side).  H <= 80 (W_hh lives in LDS). */
-typedef struct rgp_gru_scan {
-  int32_t T, B, H, reserved;
+/* ---- recurrence of the sequence-encoder back-constraint as a per-sequence persistent scan -------------------------
+ * Replaces the time loop inside PyTorch's nn.GRU / nn.RNN(tanh) / nn.LSTM as used by autoreg/rnn_encoder.py:21-83 (one
+ * layer, zero initial state, PyTorch gate orders).  The input projections gi[t] = W_ih x_t + b_ih are the caller's GEMM.
+ *   GRU : gh = W_hh h + b_hh; r = s(gi_r + gh_r); z = s(gi_z + gh_z); n = tanh(gi_n + r gh_n); h' = (1 - z) n + z h
+ *   RNN : h' = tanh(gi + W_hh h + b_hh)
+ *   LSTM: i, f, o = s(gi_. + gh_.); g = tanh(gi_g + gh_g); c' = f c + i g; h' = o tanh(c')
+ * With G = 3 / 1 / 4 gate rows per unit: gi [T][B][G H]; W_hh [G H][H]; b_hh [G H]; hseq [T][B][H] (PyTorch's (seq_len, batch,
+ * feature)); gates [T][B][NS H] (forward output, backward input): GRU r | z | n | gh_n (NS = 4), LSTM i | f | g | o | c (NS = 5),
+ * RNN none (may be NULL).
+ * Backward: g_out [T][B][H] = dL/dh_t -> dgi [T][B][G H] = dL/d gi_t and dgh [T][B][G H] = dL/d gh_t;
+ * dW_hh = sum_t dgh_t h_{t-1}^T, db_hh = sum_t dgh_t (GEMMs on the caller's side).  G H <= 256 and W_hh must fit in LDS
+ * (GRU: H <= 80, LSTM: H <= 64, RNN: H <= 140). */
+#define RGP_CELL_GRU 0
+#define RGP_CELL_RNN_TANH 1
+#define RGP_CELL_LSTM 2
+typedef struct rgp_rnn_scan {
+  int32_t T, B, H, cell;
   const double* gi;
   const double* W_hh;
   const double* b_hh;
@@ -239,9 +246,9 @@ typedef struct rgp_gru_scan {
   const double* g_out;
   double* dgi;
   double* dgh;
-} rgp_gru_scan;
-rgp_status rgp_gru_scan_forward(rgp_handle h, const rgp_gru_scan* a);
-rgp_status rgp_gru_scan_backward(rgp_handle h, const rgp_gru_scan* a);
+} rgp_rnn_scan;
+rgp_status rgp_rnn_scan_forward(rgp_handle h, const rgp_rnn_scan* a);
+rgp_status rgp_rnn_scan_backward(rgp_handle h, const rgp_rnn_scan* a);
 
 /* ---- optimiser step on device (the outer SVI loop's Adam; positive parameters live in softplus space) -------- */
 /* x, m, v: n doubles of optimiser-space parameter and Adam moments; g: gradient w.r.t. the CONSTRAINED value p;

@@ -45,8 +45,11 @@ class MlpScan(C.Structure):
                 ('g_mean', c_dp), ('g_init', c_dp), ('g_up', c_dp), ('delta', c_dp * MLP_MAX_LAYERS)]
 
 
-class GruScan(C.Structure):
-    _fields_ = [('T', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('reserved', C.c_int32),
+CELL_GRU, CELL_RNN_TANH, CELL_LSTM = 0, 1, 2
+
+
+class RnnScan(C.Structure):
+    _fields_ = [('T', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('cell', C.c_int32),
                 ('gi', c_dp), ('W_hh', c_dp), ('b_hh', c_dp), ('hseq', c_dp), ('gates', c_dp),
                 ('g_out', c_dp), ('dgi', c_dp), ('dgh', c_dp)]
 
@@ -81,8 +84,8 @@ SYMBOLS = {
     'rgp_get_stream': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     'rgp_mlp_scan_forward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
     'rgp_mlp_scan_backward': (C.c_int, [C.c_void_p, C.POINTER(MlpScan)]),
-    'rgp_gru_scan_forward': (C.c_int, [C.c_void_p, C.POINTER(GruScan)]),
-    'rgp_gru_scan_backward': (C.c_int, [C.c_void_p, C.POINTER(GruScan)]),
+    'rgp_rnn_scan_forward': (C.c_int, [C.c_void_p, C.POINTER(RnnScan)]),
+    'rgp_rnn_scan_backward': (C.c_int, [C.c_void_p, C.POINTER(RnnScan)]),
 }
 PREPARE_CHAIN_ONLY, PREPARE_ROWS_ONLY, PREPARE_ROWS_EARLY = 1, 2, 4          # rgp_layer_in.reserved for rgp_layer_prepare
 

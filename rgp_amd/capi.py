@@ -205,29 +205,37 @@ def mlp_scan_backward(handle, spec, dims, up, Ws, bs, acts, g_mean, want_g_up):
     return g_init, g_up, deltas
 
 
-def gru_scan_forward(handle, gi, W_hh, b_hh):
-    """rgp_gru_scan_forward: gi (T, B, 3H) -> (hseq (T, B, H), gates (T, B, 4H))."""
+_CELL_G = {_lib.CELL_GRU: (3, 4), _lib.CELL_RNN_TANH: (1, 0), _lib.CELL_LSTM: (4, 5)}      # gate rows, stored values per unit
+
+
+def rnn_scan_forward(handle, cell, gi, W_hh, b_hh):
+    """rgp_rnn_scan_forward: gi (T, B, G H) -> (hseq (T, B, H), gates (T, B, NS H) or None)."""
     _chk64(gi, W_hh, b_hh)
-    T, B, H3 = gi.shape
-    H = H3 // 3
-    hseq, gates = handle.new(T, B, H), handle.new(T, B, 4 * H)
-    a = _lib.GruScan()
-    a.T, a.B, a.H = T, B, H
-    a.gi, a.W_hh, a.b_hh, a.hseq, a.gates = gi.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr(), gates.data_ptr()
-    handle._check(handle.lib.rgp_gru_scan_forward(handle.h, C.byref(a)))
+    G, NS = _CELL_G[cell]
+    T, B, HG = gi.shape
+    H = HG // G
+    hseq = handle.new(T, B, H)
+    gates = handle.new(T, B, NS * H) if NS else None
+    a = _lib.RnnScan()
+    a.T, a.B, a.H, a.cell = T, B, H, cell
+    a.gi, a.W_hh, a.b_hh, a.hseq = gi.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr()
+    a.gates = gates.data_ptr() if gates is not None else None
+    handle._check(handle.lib.rgp_rnn_scan_forward(handle.h, C.byref(a)))
     return hseq, gates
 
 
-def gru_scan_backward(handle, W_hh, b_hh, hseq, gates, g_out):
-    """rgp_gru_scan_backward: g_out (T, B, H) -> (dgi, dgh), both (T, B, 3H)."""
+def rnn_scan_backward(handle, cell, W_hh, b_hh, hseq, gates, g_out):
+    """rgp_rnn_scan_backward: g_out (T, B, H) -> (dgi, dgh), both (T, B, G H)."""
     _chk64(g_out)
+    G, NS = _CELL_G[cell]
     T, B, H = hseq.shape
-    dgi, dgh = handle.new(T, B, 3 * H), handle.new(T, B, 3 * H)
-    a = _lib.GruScan()
-    a.T, a.B, a.H = T, B, H
-    a.W_hh, a.b_hh, a.hseq, a.gates = W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr(), gates.data_ptr()
+    dgi, dgh = handle.new(T, B, G * H), handle.new(T, B, G * H)
+    a = _lib.RnnScan()
+    a.T, a.B, a.H, a.cell = T, B, H, cell
+    a.W_hh, a.b_hh, a.hseq = W_hh.data_ptr(), b_hh.data_ptr(), hseq.data_ptr()
+    a.gates = gates.data_ptr() if gates is not None else None
     a.g_out, a.dgi, a.dgh = g_out.data_ptr(), dgi.data_ptr(), dgh.data_ptr()
-    handle._check(handle.lib.rgp_gru_scan_backward(handle.h, C.byref(a)))
+    handle._check(handle.lib.rgp_rnn_scan_backward(handle.h, C.byref(a)))
     return dgi, dgh
 
 

@@ -7,36 +7,38 @@ librgp_hip.so and hand back dL/dq(X), which torch.autograd pushes into the encod
 Layer l of the encoder (l = 0 is the one above the observations) takes [mean | variance] of layer l-1's output (layer 0
 takes the raw [Y | U]) -- rnn_encoder.py:98-123.
 
-GRU layers (the type the reference's mocap experiment uses) run their time loop as a per-sequence persistent scan in
-librgp_hip.so (rgp_gru_scan_forward / _backward, rgp_amd/csrc/rgp_rnn.hip) when the model attached its handle: the input
-projections of all time steps, the heads and every weight gradient stay (batched) torch GEMMs, only the strictly sequential
-recurrence moves -- the per-time-step kernel launches of the fp64 torch GRU were 95 % of a config-3 SVI step.  The parameters
-remain those of the nn.GRU module, so the torch path (other cell types, hidden width > 80, no handle) and the scan are
+The time loop of every layer (Elman/tanh RNN, LSTM or GRU cell) runs as a per-sequence persistent scan in librgp_hip.so
+(rgp_rnn_scan_forward / _backward, rgp_amd/csrc/rgp_rnn.hip) when the model attached its handle: the input projections of all
+time steps, the heads and every weight gradient stay (batched) torch GEMMs, only the strictly sequential recurrence moves --
+the per-time-step kernel launches of the fp64 torch GRU were 95 % of a config-3 SVI step.  The parameters remain those of the
+nn.RNN / nn.LSTM / nn.GRU module, so the torch path (hidden width beyond the scan's limit, no handle) and the scan are
 interchangeable and are compared in tests/test_gpu_rnn.py."""
 import torch
 import torch.nn as nn
 
 
-class _GruScanFn(torch.autograd.Function):
-    """hseq = GRU(gi; W_hh, b_hh) with h_0 = 0, gi = W_ih x + b_ih already applied; (T, B, .) layouts."""
+class _RnnScanFn(torch.autograd.Function):
+    """hseq = cell recurrence(gi; W_hh, b_hh) with zero initial state, gi = W_ih x + b_ih already applied; (T, B, .) layouts."""
 
     @staticmethod
-    def forward(ctx, handle, gi, W_hh, b_hh):
+    def forward(ctx, handle, cell, gi, W_hh, b_hh):
         from . import capi
         gi_c, W_c, b_c = gi.contiguous(), W_hh.contiguous(), b_hh.contiguous()
-        hseq, gates = capi.gru_scan_forward(handle, gi_c, W_c, b_c)
-        ctx.handle = handle
-        ctx.save_for_backward(W_c, b_c, hseq, gates)
+        hseq, gates = capi.rnn_scan_forward(handle, cell, gi_c, W_c, b_c)
+        ctx.handle, ctx.cell, ctx.has_gates = handle, cell, gates is not None
+        ctx.save_for_backward(W_c, b_c, hseq, *(() if gates is None else (gates,)))
         return hseq
 
     @staticmethod
     def backward(ctx, g_out):
         from . import capi
-        W_c, b_c, hseq, gates = ctx.saved_tensors
-        dgi, dgh = capi.gru_scan_backward(ctx.handle, W_c, b_c, hseq, gates, g_out.contiguous())
+        saved = ctx.saved_tensors
+        W_c, b_c, hseq = saved[:3]
+        gates = saved[3] if ctx.has_gates else None
+        dgi, dgh = capi.rnn_scan_backward(ctx.handle, ctx.cell, W_c, b_c, hseq, gates, g_out.contiguous())
         T, B, H = hseq.shape
-        # dW_hh = sum_t dgh_t h_{t-1}^T (h_{-1} = 0): split-K batched GEMM, the result is only 3H x H
-        dg = dgh[1:].reshape(-1, 3 * H)
+        # dW_hh = sum_t dgh_t h_{t-1}^T (h_{-1} = 0): split-K batched GEMM, the result is only G H x H
+        dg = dgh[1:].reshape(-1, dgh.shape[2])
         hp = hseq[:-1].reshape(-1, H)
         rows, chunk = dg.shape[0], 256
         nch = rows // chunk
@@ -44,7 +46,7 @@ class _GruScanFn(torch.autograd.Function):
         gW = dg[body:].t().mm(hp[body:])
         if nch > 0:
             gW = gW + torch.bmm(dg[:body].reshape(nch, chunk, -1).transpose(1, 2), hp[:body].reshape(nch, chunk, -1)).sum(0)
-        return None, dgi, gW, dgh.sum((0, 1))
+        return None, None, dgi, gW, dgh.sum((0, 1))
 
 
 class MeanVarRNN(nn.Module):
@@ -61,27 +63,42 @@ class MeanVarRNN(nn.Module):
         self.linear_var = nn.Linear(hidden_dim * ndir, output_dim)
         self.soft_plus = nn.Softplus()
 
-    handle = None               # rgp_amd.capi.Handle (set by the model): GRU time loops then run as device scans
+    handle = None               # rgp_amd.capi.Handle (set by the model): the time loops then run as device scans
     use_scan = True
 
-    def _gru_scan(self, x):
+    def _scan_cell(self):
+        """(cell id, gate rows per unit) when this layer's recurrence fits the device scan, else None."""
+        from . import _lib
+        rnn = self.rnn
+        if isinstance(rnn, nn.GRU):
+            cell, G = _lib.CELL_GRU, 3
+        elif isinstance(rnn, nn.LSTM):
+            cell, G = _lib.CELL_LSTM, 4
+        elif isinstance(rnn, nn.RNN) and rnn.nonlinearity == 'tanh':
+            cell, G = _lib.CELL_RNN_TANH, 1
+        else:
+            return None
+        Hh = rnn.hidden_size                       # G H lanes per step, and W_hh lives in LDS next to the step's vectors
+        fits = G * Hh <= 256 and (G * Hh * (Hh | 1) + 2 * G * Hh + 2 * Hh) * 8 <= 160 * 1024
+        return cell if fits else None
+
+    def _scan(self, x, cell):
         rnn, outs = self.rnn, []
         for sfx in ([''] if not rnn.bidirectional else ['', '_reverse']):
             W_ih, W_hh = getattr(rnn, 'weight_ih_l0' + sfx), getattr(rnn, 'weight_hh_l0' + sfx)
             b_ih, b_hh = getattr(rnn, 'bias_ih_l0' + sfx), getattr(rnn, 'bias_hh_l0' + sfx)
             xs = x.flip(0) if sfx else x
             gi = torch.addmm(b_ih, xs.reshape(-1, xs.shape[2]), W_ih.t()).view(xs.shape[0], xs.shape[1], -1)
-            hs = _GruScanFn.apply(self.handle, gi, W_hh, b_hh)
+            hs = _RnnScanFn.apply(self.handle, cell, gi, W_hh, b_hh)
             outs.append(hs.flip(0) if sfx else hs)
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
 
     def forward(self, x):                       # x: (seq_len, batch, input_dim); zero initial state (h_0_type='zero')
-        Hh = self.rnn.hidden_size                  # W_hh must fit in LDS next to the step's vectors: H <= 80
-        fits = 3 * Hh <= 256 and (3 * Hh * (Hh | 1) + 8 * Hh) * 8 <= 160 * 1024
-        if self.handle is not None and self.use_scan and isinstance(self.rnn, nn.GRU) and fits:
-            out = self._gru_scan(x)
+        cell = self._scan_cell() if (self.handle is not None and self.use_scan) else None
+        if cell is not None:
+            out = self._scan(x, cell)
         else:
-            out, _ = self.rnn(x)
+            out = self.rnn(x)[0]
         return self.linear_mean(out), self.soft_plus(self.linear_var(out))
 
 

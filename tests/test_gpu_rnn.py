@@ -103,17 +103,20 @@ def test_svi_steps_improve_the_bound():
     assert np.isfinite(e1) and e1 > e0, (e0, e1)
 
 
-@pytest.mark.parametrize('T,B,Din,H,bi', [(9, 3, 5, 4, False), (40, 2, 7, 20, True), (25, 1, 3, 33, False), (17, 4, 2, 80, False)])
-def test_gru_scan_matches_torch_gru(T, B, Din, H, bi):
-    """rgp_gru_scan_forward/_backward (device scan of the GRU time loop) against torch's own nn.GRU on the same module:
-    outputs, and the gradients of every weight, bias and of the input."""
+@pytest.mark.parametrize('cell,T,B,Din,H,bi', [('gru', 9, 3, 5, 4, False), ('gru', 40, 2, 7, 20, True), ('gru', 25, 1, 3, 33, False),
+                                                ('gru', 17, 4, 2, 80, False), ('rnn', 30, 3, 5, 12, True), ('rnn', 11, 2, 3, 140, False),
+                                                ('lstm', 30, 3, 5, 12, True), ('lstm', 13, 2, 4, 64, False)])
+def test_rnn_scan_matches_torch_module(cell, T, B, Din, H, bi):
+    """rgp_rnn_scan_forward/_backward (device scan of the recurrence) against torch's own nn.GRU / nn.RNN / nn.LSTM on the same
+    module: outputs, and the gradients of every weight, bias and of the input."""
     import torch
     from rgp_amd.capi import Handle
     from rgp_amd.rnn_encoder import MeanVarRNN
     Hd = Handle()
     torch.manual_seed(5)
-    lay = MeanVarRNN(Din, 3, H, 'gru', bi).double().to(Hd.device)
+    lay = MeanVarRNN(Din, 3, H, cell, bi).double().to(Hd.device)
     lay.handle = Hd
+    assert lay._scan_cell() is not None
     x = torch.randn(T, B, Din, dtype=torch.float64, device=Hd.device, requires_grad=True)
     wm = torch.randn(T, B, 3, dtype=torch.float64, device=Hd.device)
     wv = torch.randn(T, B, 3, dtype=torch.float64, device=Hd.device)
