@@ -590,39 +590,39 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   wg_gemm<true, false>(M, M, M, 1.0, c.Li, M, c.Li, M, 0.0, c.G2, M, lds);                // G2 = Li^T Li
   wg_gemm<false, true>(M, D, M, beta, c.Li, M, c.psi1Y, M, 0.0, c.bT, D, lds);            // b^T (M x D)   (:130)
   wg_gemm<true, false>(M, D, M, 1.0, c.Li, M, c.bT, D, 0.0, c.vT, D, lds);                // v^T           (:132)
-  wg_gemm<false, true>(M, M, D, 1.0, c.bT, D, c.bT, D, 0.0, c.C, M, lds);                 // C = b^T b     (:133)
-  if (c.y_uncertain) {
-    wg_gemm<false, false>(M, M, M, 1.0, c.Li, M, c.PsiR, M, 0.0, c.T1, M, lds);
-    wg_gemm<false, true>(M, M, M, beta * beta, c.T1, M, c.Li, M, 1.0, c.C, M, lds);       // + c^T c       (:137-138)
-  }
+  // From here the reference's expressions are evaluated through Kinv = Linv^T Linv and G2 = Li^T Li (7 instead of 13
+  // M x M x M products; the differences below carry the same absolute error eps ||Kinv|| as the reference's sandwiches of
+  // D I - LL^-T (C + D I) LL^-1 and I - LL^-T LL^-1, which are differences themselves):
+  //   tr C = ||b||_F^2 (+ beta^2 sum(G2 o PsiR));   Li^T C Li = v^T v (+ beta^2 G2 PsiR G2)
+  //   R = 1/2 [D Kinv - D G2 - Li^T C Li]                                                 (:140-141)
+  //   Linv^T A Linv = beta Kinv psi2 Kinv                                                 (:155)
+  //   woodbury_inv = Kinv - G2                                                            (:161)
+  double* Kinv = c.C;
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, Kinv, M, lds);
   double trC = 0.0, trA = 0.0, sR = 0.0;
-  for (int i = t; i < M; i += blockDim.x) { trC += c.C[i * M + i]; trA += c.A[i * M + i]; }
-  trC = block_sum(trC, scratch); trA = block_sum(trA, scratch);
-  // R = 1/2 Linv^T [D I - LLinv^T (C + D I) LLinv] Linv
-  for (int i = t; i < M * M; i += blockDim.x) c.T1[i] = c.C[i] + ((i / M == i % M) ? Dd : 0.0);
-  __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.LLinv, M, 0.0, c.T2, M, lds);
-  wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.T2, M, 0.0, c.T3, M, lds);
-  for (int i = t; i < M * M; i += blockDim.x) c.T3[i] += ((i / M == i % M) ? Dd : 0.0);
-  __syncthreads();
-  wg_gemm<false, false>(M, M, M, 1.0, c.T3, M, c.Linv, M, 0.0, c.T2, M, lds);
-  wg_gemm<true, false>(M, M, M, 0.5, c.Linv, M, c.T2, M, 0.0, c.R, M, lds);
-  // dL_dKmm = R - D/2 Linv^T A Linv                                                    (:155)
-  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T2, M, lds);
-  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.T3, M, lds);
+  for (int i = t; i < M * D; i += blockDim.x) trC += c.bT[i] * c.bT[i];
+  for (int i = t; i < M; i += blockDim.x) trA += c.A[i * M + i];
   for (int i = t; i < M * M; i += blockDim.x) {
-    c.dKmm[i] = c.R[i] - 0.5 * Dd * c.T3[i];
-    c.dLdpsi2[i] = beta * c.R[i];
-    sR += c.R[i] * beta * c.psi2[i];
+    c.T1[i] = Dd * (Kinv[i] - c.G2[i]);
+    if (c.y_uncertain) trC += beta * beta * c.G2[i] * c.PsiR[i];
+  }
+  trC = block_sum(trC, scratch); trA = block_sum(trA, scratch);
+  wg_gemm<false, true>(M, M, D, -1.0, c.vT, D, c.vT, D, 1.0, c.T1, M, lds);
+  if (c.y_uncertain) {
+    wg_gemm<false, false>(M, M, M, 1.0, c.G2, M, c.PsiR, M, 0.0, c.T2, M, lds);
+    wg_gemm<false, false>(M, M, M, -beta * beta, c.T2, M, c.G2, M, 1.0, c.T1, M, lds);
+  }
+  wg_gemm<false, false>(M, M, M, 1.0, c.psi2, M, Kinv, M, 0.0, c.T2, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, Kinv, M, c.T2, M, 0.0, c.T3, M, lds);
+  for (int i = t; i < M * M; i += blockDim.x) {
+    const double R = 0.5 * c.T1[i];
+    c.R[i] = R;
+    c.dKmm[i] = R - 0.5 * Dd * beta * c.T3[i];
+    c.dLdpsi2[i] = beta * R;
+    sR += R * beta * c.psi2[i];
+    if (c.winv) c.winv[i] = Kinv[i] - c.G2[i];
   }
   sR = block_sum(sR, scratch);
-  if (c.winv) {                                                                         // (:161)
-    wg_gemm<true, false>(M, M, M, -1.0, c.LLinv, M, c.LLinv, M, 0.0, c.T1, M, lds);
-    for (int i = t; i < M; i += blockDim.x) c.T1[i * M + i] += 1.0;
-    __syncthreads();
-    wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T2, M, lds);
-    wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.winv, M, lds);
-  }
   if (t == 0) {
     const double psi0b = beta * c.psi0sum[0], YRY = beta * c.yry[0];
     const double bbt = trC;                                       // ||b||^2 (+ ||c||^2) = tr C

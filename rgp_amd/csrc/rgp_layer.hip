@@ -588,10 +588,14 @@ __global__ void __launch_bounds__(256) up_latent_kernel(UpArgs a) {
 // w scales the terms that are replicated on every rank of a data-parallel collapsed bound (1 otherwise)
 __global__ void finish_elbo_kernel(const double* bound, const double* part, int npart, const double* dthetaL,
                                    double* elbo, double* gnoise, double w) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = w * bound[0];
-    for (int i = 0; i < npart; ++i) s += part[i];
-    elbo[0] = s;
+  // one wave: lane l adds partials l, l+64, ... in order, then a fixed-order wave sum (deterministic; a single thread walking
+  // the 1024 partials took 48 us of dependent loads -- on the side stream's chain of every layer step)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < npart; i += 64) s += part[i];
+  s = wave_sum_dpp(s);
+  if (threadIdx.x == 0) {
+    elbo[0] = w * bound[0] + s;
     if (gnoise) gnoise[0] = w * dthetaL[0];
   }
 }
