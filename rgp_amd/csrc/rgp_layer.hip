@@ -844,9 +844,10 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
   w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
   const size_t mm = (size_t)M * M, dm_ = (size_t)D * M;
   if (phase != 2) {
-  launch_row_offsets(s, in->n_seq, in->X_win, in->own_len, L.row_off);
-  hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->own_len, L.own_pre);
-  if (in->U_win > 0) hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->up_len, L.up_pre);
+  // row offsets, prefix sums and psi0 in one launch (psi0coef is overwritten after the chain, with the clipped noise)
+  hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
+                     in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
+                     L.psi0sum, L.psi0coef);
   launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
   launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
   launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
@@ -866,7 +867,6 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     launch_reduce(s, L.nblk2, tri, tri, L.p2_part, L.p2_tri, 1.0, 0);
     launch_unpack_tri(s, M, L.p2_tri, L.psi2);
   }
-  hipLaunchKernelGGL(psi0sum_kernel, dim3(1), dim3(64), 0, s, N, in->variance, L.psi0sum);
   }
   if (phase == 1) {                                  // hand the local statistics to the caller (vardtc.py:65-67 stub)
     RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io, L.psi0sum, sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -898,10 +898,7 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
                        c.vT, c.G2, c.beta, L.Lp, L.dYm, L.dYvar_row);
   }
   launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
-  launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
-  launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
   launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
-  launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
   {
     Psi2Out o{};
@@ -909,9 +906,15 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
     const Psi2Plan pl = psi2_plan(h, N, M, QP, false, true);
     if ((st = launch_psi2(h, false, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid))) return st;
-    launch_reduce(s, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM, L.dz2_part, L.dz2, 1.0, 0);
-    launch_reduce(s, pl.n_dl, QP, QP, L.dlam2_part, L.dlam2, 1.0, 0);
-    launch_reduce(s, pl.n_dl, 1, 1, L.wsum2_part, L.wsum2, 1.0, 0);
+    // the partial sums of the three backward passes in one launch (nothing reads them before the finalisation; the small
+    // problems of the collapsed bound are bound by the number of launches, ~5 us each)
+    const ReduceSeg segs[6] = {{L.dlam1_part, L.dlam1, L.nblk1, QP, QP},
+                               {L.lsum1_part, L.lsum1, L.nblk1, 1, 1},
+                               {L.dz1_part, L.dz1, L.nblk1, (int64_t)M * QP, (int64_t)M * QP},
+                               {L.dz2_part, L.dz2, pl.n_dz, (int64_t)QP * RGP_PSI2_TEAM, (int64_t)QP * RGP_PSI2_TEAM},
+                               {L.dlam2_part, L.dlam2, pl.n_dl, QP, QP},
+                               {L.wsum2_part, L.wsum2, pl.n_dl, 1, 1}};
+    launch_reduce_batch(s, 6, segs);
   }
   {
     FinalizeArgs f{};

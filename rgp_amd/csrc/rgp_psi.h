@@ -80,7 +80,7 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
 void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const double* part, double* out, double scale,
                    int accumulate);
 // up to REDUCE_BATCH_MAX reductions out[i] = sum_g part[g*stride + i] in one launch
-#define REDUCE_BATCH_MAX 5
+#define REDUCE_BATCH_MAX 8
 struct ReduceSeg { const double* part; double* out; int nblk; int64_t len, stride; };
 struct ReduceBatch { ReduceSeg seg[REDUCE_BATCH_MAX]; int nseg; int blk_off[REDUCE_BATCH_MAX]; };
 void launch_reduce_batch(hipStream_t s, int nseg, const ReduceSeg* segs);
