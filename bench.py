@@ -6,7 +6,7 @@ layers, M=100, SVI minibatch of 32 sub-sequences), 1..8 MI355X, one process per 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one SVI step: minibatch (32 sequences, sharded over the ranks) -> ELBO + every gradient of all three GP
-layers -> one all-reduce of the global bucket (N>1) -> Adam on the global parameters and on the touched sequences'
+layers -> all-reduce of each layer's global gradients as soon as they exist (N>1) -> Adam on the global parameters and on the touched sequences'
 latent parameters.  Inputs are resident in HBM before the timed region.  Scaling is STRONG: the minibatch is fixed at
 32 sequences and split over the ranks (32/N each), as BASELINE.json's config 4 names it.
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the fused psi2 kernel, timed with HIP
@@ -73,9 +73,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, 'launch one process per GPU (torch.distributed.run --nproc-per-node N) with --gpus N'
+    # RGP_BENCH_ONE_GPU=1 (debugging aid, never set by the driver): all ranks share GPU 0 and talk over gloo, which lets the
+    # N > 1 code path of this file be exercised on a single-GPU box; the numbers of such a run mean nothing
+    one_gpu = os.environ.get('RGP_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     cfg = dict(CONFIG4)
     n_total, T, mb = a.n_total, a.T, a.minibatch
     assert n_total % world == 0 and mb % world == 0
@@ -142,7 +150,7 @@ def main():
             'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'n_total': n_total, 'T': T, 'minibatch_sequences': mb,
-                       'rows_per_layer_per_step': mb * (T - cfg['U_win']), 'parallelism': 'dp%d (sequences sharded, one all-reduce of %d doubles per step)' % (world, m.n_global + 1)},
+                       'rows_per_layer_per_step': mb * (T - cfg['U_win']), 'parallelism': 'dp%d (sequences sharded; %d doubles of global gradients + ELBO all-reduced per step, one collective per layer)' % (world, m.n_global + 1)},
             'elbo_last_step': elbo,
             'roofline': {'bound': 'mfma', 'bound_note': 'fp64 compute (VALU); the fp64 matrix pipe is slower than the vector pipe on MI355X, see DESIGN.md', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': measured_traffic_bytes(),
