@@ -105,7 +105,8 @@ def test_svi_steps_improve_the_bound():
 
 @pytest.mark.parametrize('cell,T,B,Din,H,bi', [('gru', 9, 3, 5, 4, False), ('gru', 40, 2, 7, 20, True), ('gru', 25, 1, 3, 33, False),
                                                 ('gru', 17, 4, 2, 80, False), ('rnn', 30, 3, 5, 12, True), ('rnn', 11, 2, 3, 140, False),
-                                                ('lstm', 30, 3, 5, 12, True), ('lstm', 13, 2, 4, 64, False)])
+                                                ('lstm', 30, 3, 5, 12, True), ('lstm', 13, 2, 4, 64, False),
+                                                ('gru', 300, 4, 6, 10, False)])          # >= 1024 rows: split-K head gradients
 def test_rnn_scan_matches_torch_module(cell, T, B, Din, H, bi):
     """rgp_rnn_scan_forward/_backward (device scan of the recurrence) against torch's own nn.GRU / nn.RNN / nn.LSTM on the same
     module: outputs, and the gradients of every weight, bias and of the input."""
