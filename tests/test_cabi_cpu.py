@@ -37,6 +37,19 @@ def test_struct_fields_follow_the_header():
     import ctypes as C
     assert C.sizeof(_lib.LayerIn) == 10 * 4 + 3 * 8 + 2 * 8 + 15 * 8
     assert C.sizeof(_lib.LayerOut) == 14 * 8
+    # rgp_mlp_scan: 8 + 5 + 3 int32, then 21 pointers; rgp_rnn_scan: 4 int32, then 8 pointers (field order as in the header)
+    assert C.sizeof(_lib.MlpScan) == 16 * 4 + 21 * 8
+    assert C.sizeof(_lib.RnnScan) == 4 * 4 + 8 * 8
+    body = h[h.index('typedef struct rgp_mlp_scan {'):h.index('} rgp_mlp_scan;')]
+    pos = [body.index(f) for f in ('n_seq', 'dims[', 'reserved[3]', '* W[', '* b[', 'init_mean', '* up;', '* mean;', '* act[', 'g_mean', 'g_init',
+                                   'g_up', 'delta[')]
+    assert pos == sorted(pos)
+    assert [f for f, _ in _lib.MlpScan._fields_][8:] == ['dims', 'reserved', 'W', 'b', 'init_mean', 'up', 'mean', 'act', 'g_mean', 'g_init',
+                                                         'g_up', 'delta']
+    body = h[h.index('typedef struct rgp_rnn_scan {'):h.index('} rgp_rnn_scan;')]
+    pos = [body.index(f) for f in ('T, B, H, cell', '* gi;', 'W_hh', 'b_hh', 'hseq', 'gates', 'g_out', 'dgi', 'dgh')]
+    assert pos == sorted(pos)
+    assert [f for f, _ in _lib.RnnScan._fields_] == ['T', 'B', 'H', 'cell', 'gi', 'W_hh', 'b_hh', 'hseq', 'gates', 'g_out', 'dgi', 'dgh']
 
 
 def test_workspace_estimate_needs_no_gpu():
