@@ -340,21 +340,46 @@ class DeepAutoreg(object):
         scalar ELBO (also stored in ``grad_array[elbo_slot]``).  Latent gradients are written for the touched sequences
         only."""
         h = self.handle
-        self._flush_pipeline()
+        # chains started by the previous step of an encoder model (_restart_chains) are used instead of dropped
+        keep = bool(getattr(self, '_use_chains', False)) and self._chain_ready and getattr(self, '_rows_key', None) is None \
+            and stats_allreduce is None
+        if not keep:
+            self._flush_pipeline()
         ios, n_batch = self._build_ios(seqs, qU_ratio)
+        if keep and any(lin.N > n for (lin, _), n in zip(ios, self._chain_n)):
+            self._flush_pipeline()
+            keep = False
+        self._last_ios = ios
         try:
-            return self._evaluate_ios(ios, n_batch, stats_allreduce, world)
+            return self._evaluate_ios(ios, n_batch, stats_allreduce, world, rows_only=keep)
         except Exception:
             h.discard_prepared()          # a failed call must not leave prepared layers queued for the next one
+            self._chain_ready = False
             raise
 
-    def _evaluate_ios(self, ios, n_batch, stats_allreduce, world):
+    def _restart_chains(self):
+        """After the global parameters of every layer have been updated on the library's side stream (adam_step(post=True)):
+        start the next step's M x M chains now, so that they run under whatever the caller does before the next evaluation
+        (an encoder's backward and forward passes).  Used by the encoder models' svi_step; DeepAutoreg's own pipelined step
+        does the same per layer."""
+        from ._lib import PREPARE_CHAIN_ONLY
+        ios = getattr(self, '_last_ios', None)
+        if not (self.svi and self.pipeline and ios is not None and len(ios) <= 3):
+            return
+        for lin, _ in ios:
+            self.handle.layer_prepare(lin, PREPARE_CHAIN_ONLY)
+        self._chain_ready = True
+        self._chain_n = [lin.N for lin, _ in ios]
+
+    def _evaluate_ios(self, ios, n_batch, stats_allreduce, world, rows_only=False):
         h = self.handle
         # start K_uu / factorisations / the data-independent SVI algebra of every layer now (side stream): they need only
         # the parameters, and would otherwise sit on the critical path in front of each layer's psi passes
         if self.svi and len(ios) <= 3:
+            from ._lib import PREPARE_ROWS_ONLY
             for lin, _ in ios:
-                h.layer_prepare(lin)
+                h.layer_prepare(lin, PREPARE_ROWS_ONLY if rows_only else 0)
+            self._chain_ready = False            # consumed by the layer steps below
         if (not self.svi) and stats_allreduce is not None:
             # data-parallel collapsed bound: one all-reduce of the sufficient statistics per layer (svi_vardtc.py:65-67)
             for (lin, lout), L in zip(ios, self.layers):
@@ -808,7 +833,12 @@ class DeepAutoreg_rnn(DeepAutoreg):
             self._init_adam()
             self._enc_opt = torch.optim.Adam(self.encoder.parameters(), lr=lr, maximize=True)
         ad, h = self._adam, self.handle
-        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        carry = allreduce is None and update        # single process: the next step's chains start right after the update
+        self._use_chains = carry
+        try:
+            elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        finally:
+            self._use_chains = False
         if allreduce is not None:
             allreduce(self.grad_array[:self.n_global + 1])
             flat = self.encoder_grad_vector()
@@ -823,7 +853,9 @@ class DeepAutoreg_rnn(DeepAutoreg):
         ad['t_glob'] += 1
         G = self.n_global
         h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
-                    self.positive[:G], lr, ad['t_glob'])
+                    self.positive[:G], lr, ad['t_glob'], post=carry)
+        if carry:
+            self._restart_chains()
         for g in self._enc_opt.param_groups:
             g['lr'] = lr
         self._enc_opt.step()
@@ -907,7 +939,12 @@ class DeepAutoreg_mlp(DeepAutoreg):
         if self._enc_opt is None:
             self._enc_opt = torch.optim.Adam(self.encoder.parameters(), lr=lr, maximize=True)
         ad, h = self._adam, self.handle
-        elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        carry = allreduce is None and update        # single process: the next step's chains start right after the update
+        self._use_chains = carry
+        try:
+            elbo = self.evaluate(seqs, qU_ratio=qU_ratio)
+        finally:
+            self._use_chains = False
         if allreduce is not None:
             allreduce(self.grad_array[:self.n_global + 1])
             for p in self.encoder.nets.parameters():
@@ -918,7 +955,9 @@ class DeepAutoreg_mlp(DeepAutoreg):
         ad['t_glob'] += 1
         G = self.n_global
         h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
-                    self.positive[:G], lr, ad['t_glob'])
+                    self.positive[:G], lr, ad['t_glob'], post=carry)
+        if carry:
+            self._restart_chains()
         for g in self._enc_opt.param_groups:
             g['lr'] = lr
         self._enc_opt.step()

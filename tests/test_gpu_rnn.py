@@ -137,3 +137,25 @@ def test_rnn_scan_matches_torch_module(cell, T, B, Din, H, bi):
     np.testing.assert_allclose(gx1.cpu().numpy(), gx2.cpu().numpy(), **tol)
     for a, b in zip(gp1, gp2):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_chain_carry_over_equals_plain_steps():
+    """The encoder models start the next step's M x M chains right after the parameter update (DeepAutoreg._restart_chains);
+    the parameters after several steps, with evaluate() and a set_param() in between, equal those of the plain sequence."""
+    a, U, Y = build('gru', n_seq=4, n_total=4)
+    b, _, _ = build('gru', n_seq=4, n_total=4)
+    b.pipeline = False
+    for k in range(4):
+        ea = float(a.svi_step(slice(0, 4), lr=1e-2).item())
+        eb = float(b.svi_step(slice(0, 4), lr=1e-2).item())
+        assert abs(ea - eb) <= 1e-10 * abs(eb), (k, ea, eb)
+    ea = float(a.evaluate().item()); eb = float(b.evaluate().item())
+    assert abs(ea - eb) <= 1e-10 * abs(eb)
+    L = a.layers[0]
+    a.set_param(L, 'noise', 0.21); b.set_param(L, 'noise', 0.21)
+    for k in range(2):
+        ea = float(a.svi_step(slice(0, 2), lr=1e-2).item())
+        eb = float(b.svi_step(slice(0, 2), lr=1e-2).item())
+        assert abs(ea - eb) <= 1e-10 * abs(eb), (k, ea, eb)
+    a.handle.sync(); b.handle.sync()
+    assert float((a.param_array[:a.n_global] - b.param_array[:b.n_global]).abs().max()) <= 1e-10 * float(b.param_array[:b.n_global].abs().max())
