@@ -96,6 +96,8 @@ struct rgp_ctx {
   bool post_tail_recorded = false;
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
   int num_cu = 256;
+  unsigned vardtc_rr = 0;            // collapsed-bound layer steps rotate over the three streams
+  int vardtc_prev_slot = -1;         // workspace slot (its ev_done) of the previous collapsed-bound layer step
   // optional profiling of the psi2 launch (rgp_set_profiling)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -831,9 +831,35 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
   VarDtcChain c{};
   c.N = N; c.M = M; c.D = D; c.y_uncertain = in->y_uncertain;
   const size_t need = carve_layer(h, nullptr, N, M, Q, D, in->n_seq, L, nullptr, &c);
-  if ((st = rgp_ensure_ws(h, need))) return st;
-  carve_layer(h, h->ws, N, M, Q, D, in->n_seq, L, nullptr, &c);
-  hipStream_t s = h->stream;
+  // The layers of a collapsed-bound evaluation are independent of each other up to the final overlap-add into the latent
+  // gradients, and each is a chain of ~35 small kernels: consecutive layer steps rotate over the handle's three streams
+  // (own workspace slot each) so that they run side by side; only the latent-gradient kernels at the end wait for the
+  // previous layer step.  rgp_join / rgp_sync_status collect them (ev_done of the slots).
+  const bool rotate = h->overlap && phase == 0;
+  int slot = -1;
+  hipStream_t run = h->stream;
+  if (rotate) {
+    slot = h->slot_next;
+    h->slot_next = (slot + 1) % rgp_ctx::NSLOT;
+    if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
+    carve_layer(h, h->ws_slot[slot], N, M, Q, D, in->n_seq, L, nullptr, &c);
+    hipStream_t ring[3] = {h->stream, h->side_pre, h->side_post};
+    run = ring[h->vardtc_rr++ % 3];
+    if (run != h->stream) {                          // inputs were written by earlier main-stream work
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_main, h->stream));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(run, h->ev_main, 0));
+    }
+    if (h->done_recorded[slot]) RGP_HIP_CHECK(h, hipStreamWaitEvent(run, h->ev_done[slot], 0));
+  } else {
+    if ((st = rgp_ensure_ws(h, need))) return st;
+    carve_layer(h, h->ws, N, M, Q, D, in->n_seq, L, nullptr, &c);
+  }
+  struct StreamSwap {                                // the launch helpers below take the stream from the handle
+    rgp_handle h; hipStream_t saved;
+    StreamSwap(rgp_handle h_, hipStream_t s_) : h(h_), saved(h_->stream) { h->stream = s_; }
+    ~StreamSwap() { h->stream = saved; }
+  } swap_guard(h, run);
+  hipStream_t s = run;
   const int QP = L.zt.QP;
   const int tri = M * (M + 1) / 2;
 
@@ -926,6 +952,9 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
     launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
   }
   int npart = 0;
+  // the overlap-add into the latent gradients follows the layer above (its own_latent assigns what this layer adds to)
+  if (rotate && h->vardtc_prev_slot >= 0 && h->done_recorded[h->vardtc_prev_slot])
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_done[h->vardtc_prev_slot], 0));
   if (in->y_uncertain) {
     LatentArgs a{};
     a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
@@ -944,6 +973,11 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
                      out->gnoise, rep_w);
   if (out->woodbury_vector)
     RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.vT, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (rotate) {
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_done[slot], s));
+    h->done_recorded[slot] = true;
+    h->vardtc_prev_slot = slot;
+  }
   return last_launch(h, "rgp_layer_step(vardtc)");
 }
 
