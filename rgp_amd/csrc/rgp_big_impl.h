@@ -1,0 +1,778 @@
+// rgp_big_impl.h -- the SVI layer step for 128 < M <= 1024 inducing points (textually included by rgp_layer.hip, whose small
+// kernels -- window tables, latent overlap-add, gradient finalisation -- it shares).
+//
+// What changes against the M <= 128 path (rgp_psi.hip) and why:
+//   * psi2.  Neither the M x M forward sum (2 MB at M = 500) nor the [Q][M] dZ slab fits LDS next to the per-row state,
+//     so the fused pass splits in two:
+//       FORWARD  big_psi2_fwd_kernel: a wave owns 64 inducing rows m (lanes) x NP inducing columns m' and keeps
+//                zz[q] = z[m,q] z[m',q] in registers; it streams over the data rows with the row's scaled inverse widths as
+//                scalar operands, so psi2[m,m'] accumulates in a REGISTER (no LDS, no atomics, no barriers, fixed order).
+//                Only column groups that reach the diagonal (m' >= m) are computed: 56 % of the pairs at M = 500.
+//       BACKWARD big_psi2_bwd_kernel: as the fused kernel, thread = (data row, inducing row m of one block of <= 256), sweep
+//                over ALL m' with z[m',:] as scalar operands; dZ slab [Q][<=256] in LDS; the per-row sums over m are
+//                written per inducing block and combined by big_rowgrad_kernel.
+//     h[n,m] (the (row, m) part of the exponent) is computed once by the psi1 forward pass and read by both.
+//   * psi1 side.  Every contraction is a tall-skinny product and runs on the MFMA GEMM (rgp_gemm.hip):
+//       Lp = psi1 o (Ym Cpsi1^T),  psi1Y = Ym^T psi1,  dYm = psi1 Cpsi1 - beta Ym,  [s1 | s2 | s0] = Lp [Z | Z^2 | 1],
+//       dZ = Lp^T (e mu) - Z o (Lp^T e)        (svi_vardtc.py:164-167,192 and the psi1 gradients of GPy's rbf_psi_comp)
+//   * M x M chain: blocked, multi-workgroup (rgp_chain.hip, svi_chain_pre_big / svi_chain_post_big).
+// Everything runs on the handle's main stream: one layer step is >100 ms at these sizes.
+#include "rgp_gemm.h"
+
+#define RGP_BIG_MAX_M 1024
+
+struct BigPlan {
+  int QP, W, Mld, Mp;
+  int nI, IB, TS, NT, bwd_grid;          // backward: inducing blocks, block size, team stride, rows in flight, row workgroups
+  int NP, fwd_tasks, fwd_chunks;         // forward: columns per wave, wave tasks, row chunks
+  int sk;                                // K splits of the products that sum over the data rows
+  int rows_blk;                          // workgroups of the row-gradient kernels
+};
+
+static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
+  BigPlan p{};
+  p.QP = rgp_qp(Q);
+  p.W = 2 * p.QP + 8;
+  p.Mld = round_up(M, 64);
+  p.Mp = round_up(M, 8);
+  p.nI = (M + 255) / 256;
+  p.IB = (M + p.nI - 1) / p.nI;
+  p.TS = round_up(p.IB, 64);
+  p.NT = 512 / p.TS;
+  int64_t g = h->num_cu / p.nI;
+  if (g < 1) g = 1;
+  const int64_t maxg = (N + p.NT - 1) / p.NT;
+  if (g > maxg) g = maxg;
+  p.bwd_grid = (int)(g < 1 ? 1 : g);
+  p.NP = p.QP <= 48 ? 2 : 1;
+  const int nIB = (M + 63) / 64, nG = (M + p.NP - 1) / p.NP;
+  int tasks = 0;
+  for (int ib = 0; ib < nIB; ++ib) tasks += nG - (64 * ib) / p.NP;
+  p.fwd_tasks = tasks;
+  int64_t ch = ((int64_t)32 * h->num_cu + tasks - 1) / tasks;        // ~4 rounds of 8 waves per CU
+  if (ch > 64) ch = 64;
+  if (ch > N) ch = N;
+  p.fwd_chunks = (int)(ch < 1 ? 1 : ch);
+  int64_t sk = (N + 511) / 512;
+  p.sk = (int)(sk < 1 ? 1 : (sk > 256 ? 256 : sk));
+  int64_t rb = (N + 3) / 4;
+  p.rows_blk = (int)(rb < 1 ? 1 : (rb > 1024 ? 1024 : rb));
+  return p;
+}
+
+struct BigWs {
+  ZTerms zt; RowTerms rt;
+  double *dm, *P, *Lp, *H, *gmu, *gS, *Ym, *Yv, *dYm, *S12, *ZZ;
+  double *p2_part, *psi2, *dLs;
+  double *RP, *dz2_part, *dz2, *dlam2_part, *dlam2, *wsum2_part, *wsum2;
+  double *dzA_part, *dzA1, *dzA2, *dz1, *dlam1_part, *dlam1, *lsum1_part, *lsum1;
+  double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
+  int64_t *row_off, *own_pre, *up_pre;
+};
+
+static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, int D, int n_seq, BigWs& L, SviChain* ch) {
+  WsAlloc ws(base);
+  const int QP = p.QP;
+  const int Dd = D > 0 ? D : 1;
+  const size_t nq = (size_t)N * QP, nm = (size_t)N * M, nd = (size_t)N * Dd, mm = (size_t)M * M;
+  L.zt.M = M; L.zt.Q = Q; L.zt.QP = QP;
+  L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP);
+  L.zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM); L.zt.zd = ws.take<double>(mm); L.zt.Kuu = ws.take<double>(mm);
+  if (ch) svi_chain_carve(*ch, ws);
+  L.psi2 = ws.take<double>(mm); L.dLs = ws.take<double>(mm);
+  L.ZZ = ws.take<double>((size_t)M * p.W);
+  L.rt.N = N; L.rt.QP = QP;
+  L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq); L.rt.em = ws.take<double>(nq);
+  L.rt.g0 = ws.take<double>(N); L.rt.g1 = ws.take<double>(N);
+  L.dm = ws.take<double>(nq);
+  L.P = ws.take<double>(nm); L.Lp = ws.take<double>(nm); L.H = ws.take<double>(nm);
+  L.gmu = ws.take<double>(nq); L.gS = ws.take<double>(nq);
+  L.Ym = ws.take<double>(nd); L.Yv = ws.take<double>(nd); L.dYm = ws.take<double>(nd);
+  L.S12 = ws.take<double>((size_t)N * p.W);
+  L.p2_part = ws.take<double>((size_t)p.fwd_chunks * mm);
+  L.RP = ws.take<double>((size_t)p.nI * N * (2 * QP + 2));
+  L.dz2_part = ws.take<double>((size_t)p.bwd_grid * QP * p.Mld); L.dz2 = ws.take<double>((size_t)QP * p.Mld);
+  L.dlam2_part = ws.take<double>((size_t)p.rows_blk * QP); L.dlam2 = ws.take<double>(QP);
+  L.wsum2_part = ws.take<double>(p.rows_blk); L.wsum2 = ws.take<double>(1);
+  L.dzA_part = ws.take<double>((size_t)p.sk * M * QP); L.dzA1 = ws.take<double>((size_t)M * QP); L.dzA2 = ws.take<double>((size_t)M * QP);
+  L.dz1 = ws.take<double>((size_t)M * QP);
+  L.dlam1_part = ws.take<double>((size_t)p.rows_blk * QP); L.dlam1 = ws.take<double>(QP);
+  L.lsum1_part = ws.take<double>(p.rows_blk); L.lsum1 = ws.take<double>(1);
+  L.yry_part = ws.take<double>(2048); L.yry = ws.take<double>(1);
+  L.psi1Y_part = ws.take<double>((size_t)p.sk * Dd * M); L.psi1Y = ws.take<double>((size_t)Dd * M);
+  L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
+  L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
+  L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
+  return ws.off;
+}
+
+static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D) {
+  rgp_ctx tmp;
+  BigWs L;
+  SviChain ch{}; ch.M = M; ch.D = D > 0 ? D : 1;
+  const BigPlan p = big_plan(&tmp, N, M, Q);
+  return (int64_t)big_carve(nullptr, p, N, M, Q, D, 4096, L, &ch);
+}
+
+static inline unsigned big_nb256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// small element-wise kernels
+// ------------------------------------------------------------------------------------------------------------------
+// ZZ[m] = [ z[m, 0..QP) | z[m, 0..QP)^2 | 1 | 0 ... ]       (right operand of the row-sum product)
+__global__ void __launch_bounds__(256) big_zz_kernel(int M, int QP, int W, const double* __restrict__ Zc, double* __restrict__ ZZ) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * W) return;
+  const int m = (int)(i / W), j = (int)(i % W);
+  double v = 0.0;
+  if (j < QP) v = Zc[(size_t)m * QP + j];
+  else if (j < 2 * QP) { const double z = Zc[(size_t)m * QP + j - QP]; v = z * z; }
+  else if (j == 2 * QP) v = 1.0;
+  ZZ[i] = v;
+}
+
+// dm = -1/2 (d2 - lam): the per-row weights of the Gram term in the psi2 exponent
+__global__ void __launch_bounds__(256) big_dm_kernel(int64_t n, int QP, const double* __restrict__ d2, const double* __restrict__ lam,
+                                                      double* __restrict__ dm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dm[i] = -0.5 * (d2[i] - lam[i % QP]);
+}
+
+// dz1 = A1 - Zc o A2        (A1 = Lp^T (e mu), A2 = Lp^T e)
+__global__ void __launch_bounds__(256) big_dz1_kernel(int64_t n, const double* __restrict__ A1, const double* __restrict__ A2,
+                                                       const double* __restrict__ Zc, double* __restrict__ dz1) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz1[i] = A1[i] - Zc[i] * A2[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// psi1 forward and the (row, m) part of the psi2 exponent.  Thread = inducing row m (z[m,:] in registers); the row
+// operands are wave-uniform scalar loads.
+//   P[n,m] = exp(g1[n] - 1/2 sum_q z (e z - 2 e mu));   H[n,m] = sum_q d2 z (mu - z/4) - 1/4 sum_q lam z^2
+// ------------------------------------------------------------------------------------------------------------------
+template <int QP>
+__global__ void __launch_bounds__(256) big_psi1_fwd_kernel(const int64_t N, const int M, const double* __restrict__ Zc,
+                                                            const double* __restrict__ lam, const double* __restrict__ e1,
+                                                            const double* __restrict__ em, const double* __restrict__ d2,
+                                                            const double* __restrict__ Xmu, const double* __restrict__ g1,
+                                                            double* __restrict__ P, double* __restrict__ H) {
+  const int m = blockIdx.y * 256 + threadIdx.x;
+  const bool act = m < M;
+  const int mc = act ? m : M - 1;
+  double z[QP];
+  double ellq = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    z[q] = Zc[(size_t)mc * QP + q];
+    ellq += 0.25 * lam[q] * z[q] * z[q];
+  }
+  for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
+    const double* __restrict__ e = e1 + r * QP;
+    const double* __restrict__ mm = em + r * QP;
+    const double* __restrict__ d = d2 + r * QP;
+    const double* __restrict__ mu = Xmu + r * QP;
+    double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; q += 2) {
+      a0 += z[q] * (e[q] * z[q] - 2.0 * mm[q]);
+      a1 += z[q + 1] * (e[q + 1] * z[q + 1] - 2.0 * mm[q + 1]);
+      if (H) {
+        h0 += z[q] * d[q] * (mu[q] - 0.25 * z[q]);
+        h1 += z[q + 1] * d[q + 1] * (mu[q + 1] - 0.25 * z[q + 1]);
+      }
+    }
+    if (act) {
+      if (P) P[r * M + m] = exp(g1[r] - 0.5 * (a0 + a1));
+      if (H) H[r * M + m] = (h0 + h1) - ellq;
+    }
+  }
+}
+
+static void launch_big_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* P, double* H) {
+  const dim3 grid((unsigned)(N < 4096 ? N : 4096), (unsigned)((M + 255) / 256));
+  switch (zt.QP) {
+#define B1F(qp) case qp: hipLaunchKernelGGL((big_psi1_fwd_kernel<qp>), grid, dim3(256), 0, s, N, M, zt.Zc, zt.lam, rt.e1, rt.em, rt.d2, rt.Xmu, rt.g1, P, H); break;
+    B1F(8) B1F(16) B1F(20) B1F(24) B1F(32) B1F(40) B1F(48) B1F(56) B1F(64)
+#undef B1F
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// psi1 row gradients from the row sums S12[n] = [ s1[0..QP) | s2[0..QP) | s0 | 0.. ]  (s_k = sum_m Lp[n,m] z[m,q]^k):
+//   dmu = -e (mu s0 - s1);  dS = 1/2 e^2 S2 - 1/2 e s0,  S2 = mu^2 s0 - 2 mu s1 + s2;
+//   dinv_l[q] += -1/2 (e/lam)^2 S2 - 1/2 s0 (1 - e/lam)/lam;   lsum += s0
+// Workgroup = 4 row slots x 64 q lanes; per-workgroup partials in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) big_rows1_kernel(int64_t N, int Q, int QP, int W, const double* __restrict__ S12,
+                                                         const double* __restrict__ Xmu, const double* __restrict__ e1,
+                                                         const double* __restrict__ lam, double* __restrict__ gmu,
+                                                         double* __restrict__ gS, double* __restrict__ dlam_part,
+                                                         double* __restrict__ lsum_part) {
+  __shared__ double sm[4][64];
+  __shared__ double sl[4];
+  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double dl = 0.0, ls = 0.0;
+  const double il = (q < Q) ? 1.0 / lam[q] : 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + g; n < N; n += (int64_t)gridDim.x * 4) {
+    const double s0 = S12[n * W + 2 * QP];
+    if (q == 0) ls += s0;
+    if (q < Q) {
+      const double s1 = S12[n * W + q], s2 = S12[n * W + QP + q];
+      const double mu = Xmu[n * QP + q], e = e1[n * QP + q];
+      const double S2 = mu * mu * s0 - 2.0 * mu * s1 + s2;
+      gmu[n * QP + q] = -e * (mu * s0 - s1);
+      gS[n * QP + q] = 0.5 * e * e * S2 - 0.5 * e * s0;
+      const double el = e * il;
+      dl += -0.5 * el * el * S2 - 0.5 * s0 * (1.0 - el) * il;
+    } else if (q < QP) {
+      gmu[n * QP + q] = 0.0;
+      gS[n * QP + q] = 0.0;
+    }
+  }
+  sm[g][q] = dl;
+  if (q == 0) sl[g] = ls;
+  __syncthreads();
+  if (g == 0) {
+    if (q < QP) dlam_part[(size_t)blockIdx.x * QP + q] = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
+    if (q == 0) lsum_part[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// psi2 forward.  psi2[m,m'] = sum_n exp( g0[n] + H[n,m] + H[n,m'] + sum_q dm[n,q] z[m,q] z[m',q] ).
+// Wave task = (block of 64 inducing rows, group of NP inducing columns that reaches the block's diagonal); the products
+// zz[q] = z[m,q] z[m',q] stay in registers for the whole pass, dm[n,:], g0[n] and H[n,m'] are scalar operands.
+// part: [chunk][M][M]; entry (m, m') is written only for m' >= 64 floor(m/64) (big_psi2_unpack_kernel reads m' >= m).
+// ------------------------------------------------------------------------------------------------------------------
+template <int QP, int NP>
+__global__ void __launch_bounds__(256, 2)
+big_psi2_fwd_kernel(const int64_t N, const int M, const int ntasks, const double* __restrict__ Zc, const double* __restrict__ dm,
+                    const double* __restrict__ H, const double* __restrict__ g0, double* __restrict__ part) {
+  __shared__ double etab[PSI2_EXP_TAB];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
+  __syncthreads();
+  int task = (int)blockIdx.x * 4 + wave;
+  if (task >= ntasks) return;                                   // no barrier below
+  const int nIB = (M + 63) / 64, nG = (M + NP - 1) / NP;
+  int ib = 0;
+  for (; ib < nIB; ++ib) {
+    const int cnt = nG - (64 * ib) / NP;
+    if (task < cnt) break;
+    task -= cnt;
+  }
+  const int grp = (64 * ib) / NP + task;                        // wave-uniform
+  const int m = 64 * ib + lane;
+  const bool act = m < M;
+  const int mc = act ? m : M - 1;
+  int mp[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) mp[p] = (NP * grp + p < M) ? NP * grp + p : M - 1;
+  double zz[NP][QP], acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    acc[p] = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) zz[p][q] = Zc[(size_t)mc * QP + q] * Zc[(size_t)mp[p] * QP + q];
+  }
+  const int64_t per = (N + gridDim.y - 1) / gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  double hm = (r0 < r1) ? H[r0 * M + mc] : 0.0;
+  for (int64_t n = r0; n < r1; ++n) {
+    const double hcur = hm;
+    hm = H[((n + 1 < r1) ? n + 1 : n) * M + mc];                // next row's value lands under this row's arithmetic
+    const double* __restrict__ dn = dm + n * QP;                // wave-uniform: scalar loads
+    const double gn = g0[n];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      double c0 = hcur + (gn + H[n * M + mp[p]]), c1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; q += 2) {
+        c0 += zz[p][q] * dn[q];
+        c1 += zz[p][q + 1] * dn[q + 1];
+      }
+      acc[p] += exp_tab(c0 + c1, etab);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    if (act && NP * grp + p < M) part[((size_t)blockIdx.y * M + m) * M + NP * grp + p] = acc[p];
+}
+
+// psi2[i][j] = sum over chunks of part[chunk][min(i,j)][max(i,j)]   (fixed order)
+__global__ void __launch_bounds__(256) big_psi2_unpack_kernel(int M, int nchunk, const double* __restrict__ part,
+                                                               double* __restrict__ psi2) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)M * M) return;
+  const int i = (int)(e / M), j = (int)(e % M);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += part[((size_t)c * M + lo) * M + hi];
+  psi2[e] = s;
+}
+
+static rgp_status launch_big_psi2_fwd(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, const ZTerms& zt,
+                                      const RowTerms& rt, const double* dm, const double* H, double* part, double* psi2) {
+  const dim3 grid((unsigned)((p.fwd_tasks + 3) / 4), (unsigned)p.fwd_chunks);
+  switch (zt.QP) {
+#define B2F(qp, np) case qp: hipLaunchKernelGGL((big_psi2_fwd_kernel<qp, np>), grid, dim3(256), 0, s, N, M, p.fwd_tasks, zt.Zc, dm, H, rt.g0, part); break;
+    B2F(8, 2) B2F(16, 2) B2F(20, 2) B2F(24, 2) B2F(32, 2) B2F(40, 2) B2F(48, 2) B2F(56, 1) B2F(64, 1)
+#undef B2F
+    default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (blocked): unsupported padded Q");
+  }
+  hipLaunchKernelGGL(big_psi2_unpack_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, p.fwd_chunks, part, psi2);
+  return RGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// psi2 backward for symmetric dLs (weights W_n = dLs o psi2n).  Workgroup (row chunk, inducing block I): NT teams of TS threads
+// (whole waves), team k works on data row rr + k, thread = inducing row m of block I, sweep over all m' = 0..M-1:
+//   v = sum_m' W,  y[q] = sum_m' W z[m',q]
+// then   dZ[m,q] += d2 (v (2 mu - z) - y)            (LDS slab [QP][TS], teams one after the other: fixed order)
+//        RP[I][n] = [ sum_m v z | 1/2 sum_m z (v z + y) | sum_m v ]       (sums over the block's rows; combined over blocks
+//                                                                          by big_rowgrad_kernel)
+// ------------------------------------------------------------------------------------------------------------------
+template <int QP>
+static __device__ __forceinline__ void big_pair(const double* __restrict__ zs, const double (&dzl)[QP], double (&y)[QP], double& v,
+                                                const double base, const double hbm, const double dlv,
+                                                const double* __restrict__ etab) {
+  double c0 = base + hbm, c1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < QP; q += 2) {
+    c0 += dzl[q] * zs[q];
+    c1 += dzl[q + 1] * zs[q + 1];
+  }
+  const double p = exp_tab(c0 + c1, etab);
+  const double w = p * dlv;
+  v += w;
+#pragma unroll
+  for (int q = 0; q < QP; ++q) y[q] += w * zs[q];
+}
+
+#define BIG_T 512
+template <int QP>
+__global__ void __launch_bounds__(BIG_T, 2)
+big_psi2_bwd_kernel(const int64_t N, const int M, const int IB, const int TS, const int NT, const int Mp, const int Mld,
+                    const double* __restrict__ Zc, const double* __restrict__ lam_g, const double* __restrict__ dLs_g,
+                    const double* __restrict__ Xmu_g, const double* __restrict__ d2_g, const double* __restrict__ g0_g,
+                    const double* __restrict__ H_g, double* __restrict__ RP, double* __restrict__ dz_part) {
+  extern __shared__ double lds[];
+  constexpr int RD = 2 * QP + 2;                           // staged row: d2[QP] | mu[QP] | g0 | pad
+  constexpr int RW = 2 * QP + 2;                           // row sums:   a1[QP] | a23[QP] | w | pad
+  double* dzacc = lds;                                     // [QP][TS]
+  double* hb = dzacc + (size_t)QP * TS;                    // [NT][Mp]   h[n, 0..M) of each team's row
+  double* rowd = hb + (size_t)NT * Mp;                     // [NT][RD]
+  double* res = rowd + (size_t)NT * RD;                    // [8 waves][RW]
+  double* etab = res + 8 * RW;                             // [256]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wpt = TS >> 6;                                 // waves per team
+  const int team_raw = wave / wpt;                         // wave-uniform
+  const bool in_team = team_raw < NT;
+  const int team = in_team ? team_raw : NT - 1;
+  const int mloc = t - team_raw * TS;
+  const int i0 = (int)blockIdx.y * IB;
+  const bool act = in_team && mloc < IB && i0 + mloc < M;
+  const int mc = act ? i0 + mloc : M - 1;
+  const double* __restrict__ zrowp = Zc + (size_t)mc * QP;
+  for (int i = t; i < QP * TS; i += BIG_T) dzacc[i] = 0.0;
+  if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + NT - 1) / NT * NT;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  const double* __restrict__ dlrow = dLs_g + mc;           // dLs[m'][m]: coalesced over the lanes' rows
+  const double* hbt = hb + (size_t)team * Mp;
+  const double* rd = rowd + (size_t)team * RD;
+
+  for (int64_t rr = r0; rr < r1; rr += NT) {
+    __syncthreads();                                       // the previous iteration's readers of hb / rowd / res are done
+    for (int e = t; e < NT * Mp; e += BIG_T) {
+      const int tk = e / Mp, j = e - tk * Mp;
+      const int64_t nk = (rr + tk < r1) ? rr + tk : r1 - 1;
+      hb[e] = (j < M) ? H_g[nk * M + j] : 0.0;
+    }
+    for (int e = t; e < NT * RD; e += BIG_T) {
+      const int tk = e / RD, j = e - tk * RD;
+      const int64_t nk = (rr + tk < r1) ? rr + tk : r1 - 1;
+      double x = 0.0;
+      if (j < QP) x = d2_g[nk * QP + j];
+      else if (j < 2 * QP) x = Xmu_g[nk * QP + (j - QP)];
+      else if (j == 2 * QP) x = g0_g[nk];
+      rowd[e] = x;
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");                         // keep the per-row reloads of z[m,:] out of the registers
+    const bool valid = in_team && rr + team < r1;
+    const int64_t n = valid ? rr + team : r1 - 1;
+    double dzl[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) dzl[q] = -0.5 * zrowp[q] * (rd[q] - lam_g[q]);
+    const double base = (act && valid) ? (rd[2 * QP] + hbt[mc]) : -INFINITY;       // exp(-inf) = 0: idle lanes add nothing
+    double y[QP];
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = 0.0;
+    {
+      const int last = M - 1;
+      double dlv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
+      for (int mp = 0; mp < M; mp += 4) {
+        double dlc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dlc[u] = dlv[u];
+          dlv[u] = dlrow[(size_t)((mp + 4 + u < M) ? mp + 4 + u : last) * M];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mq = mp + u;
+          if (u == 0 || mq < M) big_pair<QP>(Zc + (size_t)mq * QP, dzl, y, v, base, hbt[mq], dlc[u], etab);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    // sums over the wave's inducing rows (fixed order), one slot per wave
+    double* wres = res + (size_t)wave * RW;
+    {
+      const double ws = wave_sum_dpp(v);
+      if (lane == 0) wres[2 * QP] = ws;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const double z = zrowp[q];
+        const double s1 = wave_sum_dpp(v * z);
+        const double s2 = wave_sum_dpp(0.5 * z * (v * z + y[q]));
+        if (lane == 0) { wres[q] = s1; wres[QP + q] = s2; }
+      }
+    }
+    // dZ accumulation  d2 (v (2 mu - z) - y), one team after the other
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = rd[q] * (v * (2.0 * rd[QP + q] - zrowp[q]) - y[q]);
+    for (int k = 0; k < NT; ++k) {
+      if (act && team_raw == k) {
+#pragma unroll
+        for (int q = 0; q < QP; ++q) dzacc[q * TS + mloc] += y[q];
+      }
+      __syncthreads();
+    }
+    // row sums of this inducing block: the team's waves in order
+    if (valid) {
+      for (int j = mloc; j < RW; j += TS) {
+        double sacc = 0.0;
+        for (int wv = team * wpt; wv < (team + 1) * wpt; ++wv) sacc += res[(size_t)wv * RW + j];
+        RP[((size_t)blockIdx.y * N + n) * RW + j] = sacc;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < QP * TS; i += BIG_T) {
+    const int q = i / TS, ml = i - q * TS;
+    if (ml < IB && i0 + ml < M) dz_part[((size_t)blockIdx.x * QP + q) * Mld + i0 + ml] = dzacc[i];
+  }
+}
+
+static size_t big_bwd_lds(const BigPlan& p) {
+  return ((size_t)p.QP * p.TS + (size_t)p.NT * p.Mp + (size_t)p.NT * (2 * p.QP + 2) + 8 * (size_t)(2 * p.QP + 2) + PSI2_EXP_TAB) * sizeof(double);
+}
+
+template <int QP>
+static hipError_t big_bwd_launch(hipStream_t s, const BigPlan& p, int64_t N, int M, const ZTerms& zt, const RowTerms& rt,
+                                 const double* dLs, const double* H, double* RP, double* dz_part) {
+  const size_t lds = big_bwd_lds(p);
+  hipError_t e = hipFuncSetAttribute((const void*)big_psi2_bwd_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((big_psi2_bwd_kernel<QP>), dim3(p.bwd_grid, p.nI), dim3(BIG_T), lds, s, N, M, p.IB, p.TS, p.NT, p.Mp, p.Mld,
+                     zt.Zc, zt.lam, dLs, rt.Xmu, rt.d2, rt.g0, H, RP, dz_part);
+  return hipSuccess;
+}
+
+// Row gradients of the psi2 term from the per-block row sums (same expressions as the fused kernel's epilogue):
+//   dmu = 2 d (a1 - mu w);  dd = -mu^2 w + 2 mu a1 - a23 + w / (2 d);  dS = -2 d^2 dd;  dinv_l += dd (d/lam)^2 - w / (2 lam)
+__global__ void __launch_bounds__(256) big_rowgrad_kernel(int64_t N, int Q, int QP, int nI, const double* __restrict__ RP,
+                                                           const double* __restrict__ Xmu, const double* __restrict__ d2,
+                                                           const double* __restrict__ lam, double* __restrict__ gmu,
+                                                           double* __restrict__ gS, int accumulate,
+                                                           double* __restrict__ dlam_part, double* __restrict__ wsum_part) {
+  __shared__ double sm[4][64];
+  __shared__ double sl[4];
+  const int RW = 2 * QP + 2;
+  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double dl = 0.0, wsum = 0.0;
+  const double il = (q < Q) ? 1.0 / lam[q] : 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + g; n < N; n += (int64_t)gridDim.x * 4) {
+    if (q < Q) {
+      double w = 0.0, a1 = 0.0, a23 = 0.0;
+      for (int b = 0; b < nI; ++b) {
+        const double* rp = RP + ((size_t)b * N + n) * RW;
+        w += rp[2 * QP];
+        a1 += rp[q];
+        a23 += rp[QP + q];
+      }
+      const double mu = Xmu[n * QP + q], dq = d2[n * QP + q];
+      const double dmu = 2.0 * dq * (a1 - mu * w);
+      const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
+      const double dS = -2.0 * dq * dq * dd;
+      if (accumulate) { gmu[n * QP + q] += dmu; gS[n * QP + q] += dS; }
+      else { gmu[n * QP + q] = dmu; gS[n * QP + q] = dS; }
+      dl += dd * (dq * il) * (dq * il) - 0.5 * w * il;
+      if (q == 0) wsum += w;
+    } else if (q < QP && !accumulate) {
+      gmu[n * QP + q] = 0.0;
+      gS[n * QP + q] = 0.0;
+    }
+  }
+  sm[g][q] = dl;
+  if (q == 0) sl[g] = wsum;
+  __syncthreads();
+  if (g == 0) {
+    if (q < QP) dlam_part[(size_t)blockIdx.x * QP + q] = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
+    if (q == 0) wsum_part[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+  }
+}
+
+// backward pass + its reductions: row gradients into gmu / gS, dz2 [QP][Mld], dlam2 [QP], wsum2 [1]
+static rgp_status launch_big_psi2_bwd(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, const ZTerms& zt,
+                                      const RowTerms& rt, const double* dLs, const double* H, BigWs& L, int accumulate) {
+  hipError_t e = hipSuccess;
+  switch (zt.QP) {
+#define B2B(qp) case qp: e = big_bwd_launch<qp>(s, p, N, M, zt, rt, dLs, H, L.RP, L.dz2_part); break;
+    B2B(8) B2B(16) B2B(20) B2B(24) B2B(32) B2B(40) B2B(48) B2B(56) B2B(64)
+#undef B2B
+    default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (blocked): unsupported padded Q");
+  }
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 backward (blocked): ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(big_rowgrad_kernel, dim3(p.rows_blk), dim3(256), 0, s, N, Q, p.QP, p.nI, L.RP, rt.Xmu, rt.d2, zt.lam, L.gmu,
+                     L.gS, accumulate, L.dlam2_part, L.wsum2_part);
+  const ReduceSeg segs[3] = {{L.dz2_part, L.dz2, p.bwd_grid, (int64_t)p.QP * p.Mld, (int64_t)p.QP * p.Mld},
+                             {L.dlam2_part, L.dlam2, p.rows_blk, p.QP, p.QP},
+                             {L.wsum2_part, L.wsum2, p.rows_blk, 1, 1}};
+  launch_reduce_batch(s, 3, segs);
+  return RGP_OK;
+}
+
+// psi1 backward for a given Lp = dL_dpsi1 o psi1 (N x M): row gradients (=), dz1, dlam1, lsum1
+static void launch_big_psi1_bwd(hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt,
+                                BigWs& L) {
+  const int QP = p.QP;
+  {                                                          // [s1 | s2 | s0] = Lp [Z | Z^2 | 1]
+    GemmArgs g;
+    g.m = (int)N; g.n = p.W; g.k = M; g.A = L.Lp; g.lda = M; g.B = L.ZZ; g.ldb = p.W; g.C = L.S12; g.ldc = p.W;
+    launch_gemm(s, g);
+  }
+  hipLaunchKernelGGL(big_rows1_kernel, dim3(p.rows_blk), dim3(256), 0, s, N, Q, QP, p.W, L.S12, rt.Xmu, rt.e1, zt.lam, L.gmu, L.gS,
+                     L.dlam1_part, L.lsum1_part);
+  for (int k = 0; k < 2; ++k) {                              // A1 = Lp^T (e mu), A2 = Lp^T e   (sums over the data rows: split K)
+    GemmArgs g;
+    g.m = M; g.n = QP; g.k = (int)N; g.A = L.Lp; g.lda = M; g.ta = 1; g.B = k == 0 ? rt.em : rt.e1; g.ldb = QP;
+    g.C = L.dzA_part; g.ldc = QP; g.splits = p.sk; g.split_stride = (int64_t)M * QP;
+    if (p.sk == 1) g.C = k == 0 ? L.dzA1 : L.dzA2;
+    launch_gemm(s, g);
+    if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)M * QP, (int64_t)M * QP, L.dzA_part, k == 0 ? L.dzA1 : L.dzA2, 1.0, 0);
+  }
+  hipLaunchKernelGGL(big_dz1_kernel, dim3(big_nb256((int64_t)M * QP)), dim3(256), 0, s, (int64_t)M * QP, L.dzA1, L.dzA2, zt.Zc, L.dz1);
+  const ReduceSeg segs[2] = {{L.dlam1_part, L.dlam1, p.rows_blk, QP, QP}, {L.lsum1_part, L.lsum1, p.rows_blk, 1, 1}};
+  launch_reduce_batch(s, 2, segs);
+}
+
+static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q) {
+  if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
+  if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
+  if (rgp_qp(Q) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
+  if (N > 0x7fffffffLL / 2) return rgp_fail(h, RGP_ERR_BAD_ARG, "more than 2^30 data rows in one call");
+  return RGP_OK;
+}
+
+// ==================================================================================================================
+// unit entry points (rgp_psi_forward / rgp_psi_backward for M > 128)
+// ==================================================================================================================
+static rgp_status big_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
+                                  const double* variance, const double* inv_l, double* psi1, double* psi2) {
+  rgp_status st = big_check(h, N, M, Q);
+  if (st) return st;
+  const BigPlan p = big_plan(h, N, M, Q);
+  BigWs L;
+  const size_t need = big_carve(nullptr, p, N, M, Q, 1, 1, L, nullptr);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  big_carve(h->ws, p, N, M, Q, 1, 1, L, nullptr);
+  hipStream_t s = h->stream;
+  launch_prep_z(s, M, Q, p.QP, Z, variance, inv_l, RGP_JITTER, L.zt);
+  launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
+  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, psi1, psi2 ? L.H : nullptr);
+  if (psi2) {
+    hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * p.QP)), dim3(256), 0, s, N * p.QP, p.QP, L.rt.d2, L.zt.lam, L.dm);
+    if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, psi2))) return st;
+  }
+  return last_launch(h, "rgp_psi_forward (blocked)");
+}
+
+__global__ void __launch_bounds__(256) big_mul_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] * b[i];
+}
+__global__ void __launch_bounds__(256) big_fill_kernel(int64_t n, double* __restrict__ x, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
+                                   const double* variance, const double* inv_l, double dL_dpsi0_sum, const double* dL_dpsi1,
+                                   const double* dL_dpsi2, double* dvar, double* dinv_l, double* dZ, double* dmu, double* dS) {
+  rgp_status st = big_check(h, N, M, Q);
+  if (st) return st;
+  const BigPlan p = big_plan(h, N, M, Q);
+  BigWs L;
+  const size_t need = big_carve(nullptr, p, N, M, Q, 1, 1, L, nullptr);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  big_carve(h->ws, p, N, M, Q, 1, 1, L, nullptr);
+  hipStream_t s = h->stream;
+  const int QP = p.QP;
+  launch_prep_z(s, M, Q, QP, Z, variance, inv_l, RGP_JITTER, L.zt);
+  launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
+  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, dL_dpsi1 ? L.P : nullptr, dL_dpsi2 ? L.H : nullptr);
+  if (dL_dpsi1) {
+    hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
+    hipLaunchKernelGGL(big_mul_kernel, dim3(big_nb256(N * M)), dim3(256), 0, s, N * M, dL_dpsi1, L.P, L.Lp);
+    launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
+  } else {
+    hipLaunchKernelGGL(big_fill_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.gmu, 0.0);
+    hipLaunchKernelGGL(big_fill_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.gS, 0.0);
+  }
+  if (dL_dpsi2) {
+    hipLaunchKernelGGL(symmetrise_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
+    hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
+    if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2))) return st;
+    if ((st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1))) return st;
+  }
+  FinalizeArgs f{};
+  f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = variance;
+  f.Kj = nullptr; f.dKmm = nullptr;
+  f.dLs = dL_dpsi2 ? L.dLs : nullptr; f.psi2 = dL_dpsi2 ? L.psi2 : nullptr;
+  f.dz1 = dL_dpsi1 ? L.dz1 : nullptr; f.dz2 = dL_dpsi2 ? L.dz2 : nullptr; f.dz2_ld = p.Mld;
+  f.dlam1 = dL_dpsi1 ? L.dlam1 : nullptr; f.dlam2 = dL_dpsi2 ? L.dlam2 : nullptr;
+  f.lsum1 = dL_dpsi1 ? L.lsum1 : nullptr; f.wsum2 = dL_dpsi2 ? L.wsum2 : nullptr;
+  f.dk_scale = 1.0; f.psi0_coef = dL_dpsi0_sum; f.psi0_dev = nullptr; f.psi0_dev_scale = 0.0;
+  f.gZ = dZ; f.ginv_l = dinv_l; f.gvariance = dvar;
+  launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
+  const int64_t nq = N * Q;
+  hipLaunchKernelGGL(unpad_kernel, dim3(big_nb256(nq)), dim3(256), 0, s, N, Q, QP, L.gmu, dmu);
+  hipLaunchKernelGGL(unpad_kernel, dim3(big_nb256(nq)), dim3(256), 0, s, N, Q, QP, L.gS, dS);
+  return last_launch(h, "rgp_psi_backward (blocked)");
+}
+
+// ==================================================================================================================
+// the SVI layer step (rgp_layer_step, M > 128): same inputs, outputs and arithmetic as the M <= 128 step
+// ==================================================================================================================
+static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out) {
+  const int M = in->M, D = in->D;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  const int64_t N = in->N;
+  rgp_status st = big_check(h, N, M, Q);
+  if (st) return st;
+  if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
+  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
+  if (D < 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be positive");
+  const BigPlan p = big_plan(h, N, M, Q);
+  const int QP = p.QP;
+  BigWs L;
+  SviChain c{};
+  c.N = N; c.M = M; c.D = D; c.qU_ratio = in->qU_ratio;
+  const size_t need = big_carve(nullptr, p, N, M, Q, D, in->n_seq, L, &c);
+  if ((st = rgp_ensure_ws(h, need))) return st;                 // also joins the side streams (parameter updates issued there)
+  big_carve(h->ws, p, N, M, Q, D, in->n_seq, L, &c);
+  hipStream_t s = h->stream;
+
+  WindowSpec w{};
+  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
+  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
+  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
+  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+
+  // tables, Z terms, row terms
+  hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
+                     in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
+                     L.psi0sum, L.psi0coef);
+  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+  hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
+  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+  hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
+
+  // data-independent algebra: K_uu factor, Cpsi1, dL/dpsi2, KL terms
+  c.Kj = L.zt.Kuu; c.noise = in->noise; c.qU_m = in->qU_m; c.qU_W = in->qU_W; c.qU_a = in->qU_a; c.status = h->status;
+  c.dLs_sym = L.dLs;
+  c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
+  c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv;
+  if ((st = launch_svi_chain_pre(h, c, s))) return st;
+
+  // psi1 side
+  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
+  {                                                          // Lp = psi1 o (Ym Cpsi1^T)              (svi_vardtc.py:164-167)
+    GemmArgs g;
+    g.m = (int)N; g.n = M; g.k = D; g.A = L.Ym; g.lda = D; g.B = c.Cpsi1; g.ldb = D; g.tb = 1; g.C = L.Lp; g.ldc = M;
+    g.E = L.P; g.lde = M;
+    launch_gemm(s, g);
+  }
+  {                                                          // psi1Y = Ym^T psi1  (D x M)            (svi_vardtc.py:57)
+    GemmArgs g;
+    g.m = D; g.n = M; g.k = (int)N; g.A = L.Ym; g.lda = D; g.ta = 1; g.B = L.P; g.ldb = M;
+    g.C = p.sk > 1 ? L.psi1Y_part : L.psi1Y; g.ldc = M; g.splits = p.sk; g.split_stride = (int64_t)D * M;
+    launch_gemm(s, g);
+    if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
+  }
+  if (in->y_uncertain) {                                     // dL/dYmean = psi1 Cpsi1 - beta Ym           (svi_vardtc.py:192)
+    GemmArgs g;
+    g.m = (int)N; g.n = D; g.k = M; g.A = L.P; g.lda = M; g.B = c.Cpsi1; g.ldb = D; g.C = L.dYm; g.ldc = D;
+    g.gamma = 1.0; g.g_dev = c.scal + 5; g.Cin = L.Ym; g.ldcin = D;
+    launch_gemm(s, g);
+  }
+  launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
+
+  // psi2: forward sum, then backward with the symmetrised dL/dpsi2 of the chain
+  prof_begin(h, (double)N * M * M * Q);
+  st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
+  if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
+  prof_end(h);
+  if (st) return st;
+
+  // latent gradients
+  int npart = 0;
+  if (in->y_uncertain) {
+    LatentArgs a{};
+    a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
+    a.noise = in->noise; a.dYvar_row = nullptr; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var;
+    a.elbo_part = L.elbo_part;
+    hipLaunchKernelGGL(own_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+    npart = LAT_BLOCKS;
+  }
+  if (out->g_up_mean && in->U_win > 0) {
+    UpArgs a{};
+    a.w = w; a.QP = QP; a.up_rows = in->up_rows; a.up_pre = L.up_pre; a.gmu = L.gmu; a.gS = L.gS;
+    a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
+    hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+  }
+  // data-dependent algebra + kernel-hyperparameter gradients
+  if ((st = launch_svi_chain_post(h, c, s))) return st;
+  {
+    FinalizeArgs f{};
+    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
+    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2; f.dz2_ld = p.Mld;
+    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
+    f.dk_scale = 1.0; f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
+    launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
+  }
+  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
+                     out->gnoise, 1.0);
+  if (out->woodbury_vector)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.Kinv_mu, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (h->overlap) {
+    // rgp_adam_step_post / the caller's all-reduce run on the side stream: order them behind this step
+    RGP_HIP_CHECK(h, hipEventRecord(h->ev_stats, s));
+    RGP_HIP_CHECK(h, hipStreamWaitEvent(h->side_post, h->ev_stats, 0));
+  }
+  return last_launch(h, "rgp_layer_step (blocked)");
+}

@@ -14,6 +14,7 @@ struct SviChain {
   double *Sinv, *Wi;                                    // S^-1 and woodbury_inv, produced by stage 1c for stage 2
   double *gmu, *Kinv_mu, *Cpsi1, *Ybt, *gqm;
   double *scal, *bound, *dthetaL;
+  double *bigD = nullptr, *bigP = nullptr;              // M > 128 only: inverses of the diagonal blocks, panel buffer
   // optional outputs (device, caller owned; may be null)
   double *gqU_m, *gqU_W, *gqU_a, *winv;
   int* status;

@@ -6,6 +6,7 @@
 // the 1e-6 jitter the reference uses) -- every triangular solve of the reference becomes a small GEMM.
 // The factorisations run in LDS (one padded M x M matrix, M <= 140); GEMMs run on L2-resident workspace matrices.
 #include "rgp_chain.h"
+#include "rgp_gemm.h"
 
 #include <math.h>
 
@@ -168,12 +169,12 @@ static __device__ void trtri16_wave(double* L, int ld, int nb) {
 }
 
 // blocked right-looking Cholesky, lower, in place.  `ext` = LDS_FACT_EXTRA doubles of LDS behind the matrix.
-static __device__ void lds_chol_blocked(double* A, int M, int ld, int* status, double* ext) {
+static __device__ void lds_chol_blocked(double* A, int M, int ld, int* status, double* ext, int piv_base = 0) {
   double* rdiag = ext + (size_t)CH_MAX_M * FB;
   const int t = threadIdx.x, T = blockDim.x;
   for (int kb = 0; kb < M; kb += FB) {
     const int nb = (M - kb < FB) ? (M - kb) : FB;
-    if (t < 64) chol16_wave(A + kb * ld + kb, ld, nb, status, kb, rdiag);
+    if (t < 64) chol16_wave(A + kb * ld + kb, ld, nb, status, piv_base + kb, rdiag);
     __syncthreads();
     const int r0 = kb + nb, nrem = M - r0;
     if (nrem > 0) {
@@ -518,8 +519,233 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   }
 }
 
+
+// ==================================================================================================================
+// M > 128: the same algebra with the factorisations blocked over workgroups and every M x M x M product on the MFMA
+// GEMM (rgp_gemm.hip).  One stream, ~90 launches per layer: at these sizes a layer step spends >100 ms in the psi2 passes,
+// so the chain is not hidden behind side streams.
+//   Cholesky (right-looking, block NB_BIG = 128): diagonal block factored AND inverted in LDS by one workgroup
+//   (lds_chol_blocked / lds_trtri_blocked above); panel A21 <- A21 L11^-T and trailing update A22 -= P P^T as GEMMs.
+//   Inverse factor: Linv[b, 0:b] = -L_bb^-1 (L[b, 0:b] Linv[0:b, 0:b]), block row after block row (two GEMMs each).
+// ==================================================================================================================
+#define NB_BIG 128
+
+static size_t big_fact_doubles(int M) {
+  const size_t nblk = (size_t)(M + NB_BIG - 1) / NB_BIG;
+  return nblk * NB_BIG * NB_BIG + (size_t)M * NB_BIG;
+}
+static void big_fact_carve(int M, double*& bigD, double*& bigP, WsAlloc& ws) {
+  const size_t nblk = (size_t)(M + NB_BIG - 1) / NB_BIG;
+  bigD = ws.take<double>(nblk * NB_BIG * NB_BIG);
+  bigP = ws.take<double>((size_t)M * NB_BIG);
+}
+
+// A11 = nb x nb block at (kb, kb) of the M x M matrix A: A11 <- chol(A11) (strict upper part of the block zeroed),
+// Dinv <- A11^-1 (nb x nb, row stride NB_BIG); logdet[0] (+)= sum log diag(chol)   (first block assigns)
+__global__ void __launch_bounds__(CH_THREADS) chol_diag_kernel(double* __restrict__ A, int ld, int kb, int nb,
+                                                                double* __restrict__ Dinv, double* logdet, int* status) {
+  extern __shared__ double lds[];
+  __shared__ double scratch[16];
+  const int t = threadIdx.x, ldl = nb + 1;
+  for (int i = t; i < nb * nb; i += blockDim.x) lds[(i / nb) * ldl + (i % nb)] = A[(size_t)(kb + i / nb) * ld + kb + (i % nb)];
+  __syncthreads();
+  lds_chol_blocked(lds, nb, ldl, status, lds + (size_t)nb * ldl, kb);
+  const double ldsum = block_sum((t < nb) ? log(lds[t * ldl + t]) : 0.0, scratch);
+  for (int i = t; i < nb * nb; i += blockDim.x) A[(size_t)(kb + i / nb) * ld + kb + (i % nb)] = lds[(i / nb) * ldl + (i % nb)];
+  __syncthreads();
+  lds_trtri_blocked(lds, nb, ldl, lds + (size_t)nb * ldl);
+  for (int i = t; i < nb * nb; i += blockDim.x) {
+    const int r = i / nb, cc = i % nb;
+    Dinv[(size_t)r * NB_BIG + cc] = (cc <= r) ? lds[r * ldl + cc] : 0.0;
+  }
+  if (t == 0 && logdet) logdet[0] = (kb == 0 ? 0.0 : logdet[0]) + ldsum;
+}
+
+// dst[(r0 + i) * ldd + c0 + j] = src[i * lds_ + j], i < rows, j < cols
+__global__ void __launch_bounds__(256) copy_block_kernel(int rows, int cols, const double* __restrict__ src, int lds_,
+                                                          double* __restrict__ dst, int ldd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)rows * cols) dst[(size_t)(e / cols) * ldd + (e % cols)] = src[(size_t)(e / cols) * lds_ + (e % cols)];
+}
+// mode 0: zero the strict upper triangle of the M x M matrix; mode 1: zero everything
+__global__ void __launch_bounds__(256) zero_kernel(int M, double* __restrict__ A, int mode) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)M * M && (mode == 1 || (e % M) > (e / M))) A[e] = 0.0;
+}
+static inline unsigned nblocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// A (M x M, symmetric positive definite, full storage) <- its lower Cholesky factor; Dinv <- inverses of the diagonal blocks
+static rgp_status chol_big(rgp_handle h, hipStream_t s, double* A, int M, double* Dinv, double* Ptmp, double* logdet, int* status) {
+  const size_t lds = ((size_t)NB_BIG * (NB_BIG + 1) + LDS_FACT_EXTRA) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("blocked Cholesky LDS attr: ") + hipGetErrorString(e));
+  for (int kb = 0, b = 0; kb < M; kb += NB_BIG, ++b) {
+    const int nb = (M - kb < NB_BIG) ? M - kb : NB_BIG;
+    double* Db = Dinv + (size_t)b * NB_BIG * NB_BIG;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(CH_THREADS), lds, s, A, M, kb, nb, Db, logdet, status);
+    const int r0 = kb + nb, rem = M - r0;
+    if (rem > 0) {
+      gemm(s, rem, nb, nb, 1.0, A + (size_t)r0 * M + kb, M, false, Db, NB_BIG, true, 0.0, Ptmp, NB_BIG);       // P = A21 L11^-T
+      hipLaunchKernelGGL(copy_block_kernel, dim3(nblocks256((int64_t)rem * nb)), dim3(256), 0, s, rem, nb, Ptmp, NB_BIG,
+                         A + (size_t)r0 * M + kb, M);
+      gemm(s, rem, rem, nb, -1.0, Ptmp, NB_BIG, false, Ptmp, NB_BIG, true, 1.0, A + (size_t)r0 * M + r0, M);  // A22 -= P P^T
+    }
+  }
+  hipLaunchKernelGGL(zero_kernel, dim3(nblocks256((int64_t)M * M)), dim3(256), 0, s, M, A, 0);
+  return RGP_OK;
+}
+
+// Linv <- L^-1 for the lower-triangular L whose diagonal-block inverses are in Dinv; Tbuf holds NB_BIG x M doubles
+static void trtri_big(hipStream_t s, const double* L, int M, const double* Dinv, double* Linv, double* Tbuf) {
+  hipLaunchKernelGGL(zero_kernel, dim3(nblocks256((int64_t)M * M)), dim3(256), 0, s, M, Linv, 1);
+  for (int kb = 0, b = 0; kb < M; kb += NB_BIG, ++b) {
+    const int nb = (M - kb < NB_BIG) ? M - kb : NB_BIG;
+    const double* Db = Dinv + (size_t)b * NB_BIG * NB_BIG;
+    hipLaunchKernelGGL(copy_block_kernel, dim3(nblocks256((int64_t)nb * nb)), dim3(256), 0, s, nb, nb, Db, NB_BIG,
+                       Linv + (size_t)kb * M + kb, M);
+    if (kb > 0) {
+      gemm(s, nb, kb, kb, 1.0, L + (size_t)kb * M, M, false, Linv, M, false, 0.0, Tbuf, M);          // T = L[b, 0:b] Linv[0:b, 0:b]
+      gemm(s, nb, kb, nb, -1.0, Db, NB_BIG, false, Tbuf, M, false, 0.0, Linv + (size_t)kb * M, M);   // Linv[b, 0:b] = -L_bb^-1 T
+    }
+  }
+}
+
+// ---- element-wise glue of the blocked SVI chain (same identities as the single-workgroup kernels above) -----------------
+// scal: [0] sum log diag Lm, [1] sum log diag Ls, [2] tr B, [3] beta, [4] beta/2, [5] -beta, [6] 2/(beta D)
+__global__ void big_scal_kernel(SviChain c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double beta = 1.0 / c.noise[0];
+    c.scal[3] = beta; c.scal[4] = 0.5 * beta; c.scal[5] = -beta; c.scal[6] = 2.0 / (beta * (double)c.D);
+  }
+}
+// what: 0  Cpsi1 = beta Kinv_mu                      (M x D)
+//       1  S += a I ; T1 = D S                       (M x M)
+//       2  T1 = D I - B
+//       3  dLs_sym = 1/2 (dLdpsi2 + dLdpsi2^T)
+//       4  Wi = 2/(beta D) dLdpsi2
+//       5  dKmm, Gv                                  (svi_vardtc.py:129-133,147,213 as in svi_chain_post_kernel)
+//       6  gqm = Ybt - ratio Kinv_mu                 (M x D)
+//       7  T1 = Gv + Gv^T
+//       8  copy S to LsInv's storage (factored in place there)
+__global__ void __launch_bounds__(256) big_elem_kernel(SviChain c, int what) {
+  const int M = c.M, D = c.D;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t mm = (int64_t)M * M, md = (int64_t)M * D;
+  const double Dd = (double)D;
+  const int r = (int)(i / M), cc = (int)(i % M);
+  const int64_t it = (int64_t)cc * M + r;
+  switch (what) {
+    case 0: if (i < md) c.Cpsi1[i] = c.scal[3] * c.Kinv_mu[i]; break;
+    case 1: if (i < mm) { const double sv = c.S[i] + (r == cc ? c.qU_a[0] : 0.0); c.S[i] = sv; c.T1[i] = Dd * sv; } break;
+    case 2: if (i < mm) c.T1[i] = (r == cc ? Dd : 0.0) - c.B[i]; break;
+    case 3: if (i < mm && c.dLs_sym) c.dLs_sym[i] = 0.5 * (c.dLdpsi2[i] + c.dLdpsi2[it]); break;
+    case 4: if (i < mm) c.Wi[i] = c.scal[6] * c.dLdpsi2[i]; break;
+    case 5: if (i < mm) {
+      const double ratio = c.qU_ratio, rb = ratio / c.scal[3];
+      c.dKmm[i] = -(c.T2[i] + c.T2[it]) - 0.25 * Dd * (c.mA[i] + c.mA[it]) - 0.5 * (c.T3[i] + c.T3[it]) - rb * c.dLdpsi2[i];
+      c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);
+    } break;
+    case 6: if (i < md) c.gqm[i] = c.Ybt[i] - c.qU_ratio * c.Kinv_mu[i]; break;
+    case 7: if (i < mm) c.T1[i] = c.Gv[i] + c.Gv[it]; break;
+    case 8: if (i < mm) c.LsInv[i] = c.S[i]; break;
+    default: break;
+  }
+}
+static void big_elem(hipStream_t s, const SviChain& c, int what, bool md) {
+  const int64_t n = md ? (int64_t)c.M * c.D : (int64_t)c.M * c.M;
+  hipLaunchKernelGGL(big_elem_kernel, dim3(nblocks256(n)), dim3(256), 0, s, c, what);
+}
+__global__ void __launch_bounds__(CH_THREADS) big_trace_kernel(int M, const double* __restrict__ A, double* out) {
+  __shared__ double scratch[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) s += A[(size_t)i * M + i];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) out[0] = s;
+}
+// the scalars of stage 2 (svi_vardtc.py:121-123,139,209; layers.py:76,176) and the plain copies into the caller's outputs
+__global__ void __launch_bounds__(CH_THREADS) big_final_kernel(SviChain c) {
+  __shared__ double scratch[16];
+  const int M = c.M, D = c.D, t = threadIdx.x;
+  const double Dd = (double)D, Nd = (double)c.N;
+  const double beta = c.scal[3], ratio = c.qU_ratio;
+  double sP = 0.0, gY = 0.0, tr = 0.0;
+  for (int64_t i = t; i < (int64_t)M * M; i += blockDim.x) sP += c.dLdpsi2[i] * c.psi2[i];
+  for (int64_t i = t; i < (int64_t)M * D; i += blockDim.x) gY += c.Cpsi1[i] * c.psi1Y[(size_t)(i % D) * M + i / D];
+  for (int i = t; i < M; i += blockDim.x) tr += c.Gv[(size_t)i * M + i];
+  sP = block_sum(sP, scratch); gY = block_sum(gY, scratch); tr = block_sum(tr, scratch);
+  if (c.gqU_m) for (int64_t i = t; i < (int64_t)M * D; i += blockDim.x) c.gqU_m[i] = c.gqm[i];
+  if (c.winv) for (int64_t i = t; i < (int64_t)M * M; i += blockDim.x) c.winv[i] = c.Wi[i];
+  if (t == 0) {
+    const double data_fit = -0.5 * Dd * beta * c.psi0sum[0] - 0.5 * beta * c.yry[0] + sP + gY;
+    const double logL = -0.5 * Nd * Dd * LOG_2PI + 0.5 * Dd * Nd * log(beta) + data_fit;
+    const double KL = -0.5 * Dd * M - Dd * c.scal[1] + Dd * c.scal[0] + 0.5 * c.scal[2];
+    if (c.gqU_a) c.gqU_a[0] = tr;
+    c.bound[0] = logL - ratio * KL;
+    c.dthetaL[0] = -0.5 * Dd * Nd * beta - data_fit * beta;
+  }
+}
+
+static rgp_status svi_chain_pre_big(rgp_handle h, const SviChain& c, hipStream_t s, hipEvent_t ev_after_a, hipEvent_t ev_after_b) {
+  const int M = c.M, D = c.D;
+  rgp_status st;
+  hipError_t e;
+  hipLaunchKernelGGL(big_scal_kernel, dim3(1), dim3(64), 0, s, c);
+  // ---- (a) Lm = chol(K), Linv; gmu = Linv mu; Kinv_mu = Linv^T gmu; Cpsi1 = beta Kinv_mu          (svi_vardtc.py:93-97,153,164-167)
+  RGP_HIP_CHECK(h, hipMemcpyAsync(c.T3, c.Kj, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if ((st = chol_big(h, s, c.T3, M, c.bigD, c.bigP, c.scal + 0, c.status))) return st;
+  trtri_big(s, c.T3, M, c.bigD, c.Linv, c.bigP);
+  gemm(s, M, D, M, 1.0, c.Linv, M, false, c.qU_m, D, false, 0.0, c.gmu, D);
+  gemm(s, M, D, M, 1.0, c.Linv, M, true, c.gmu, D, false, 0.0, c.Kinv_mu, D);
+  big_elem(s, c, 0, true);
+  if (ev_after_a && (e = hipEventRecord(ev_after_a, s)) != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
+  // ---- (b) S = W W^T + a I; V = D S + mu mu^T; B = Linv V Linv^T; dL_dpsi2 = beta/2 Linv^T (D I - B) Linv      (layers.py:71, :111,169)
+  gemm(s, M, M, M, 1.0, c.qU_W, M, false, c.qU_W, M, true, 0.0, c.S, M);
+  big_elem(s, c, 1, false);
+  gemm(s, M, M, D, 1.0, c.qU_m, D, false, c.qU_m, D, true, 1.0, c.T1, M);
+  gemm(s, M, M, M, 1.0, c.Linv, M, false, c.T1, M, false, 0.0, c.T2, M);
+  gemm(s, M, M, M, 1.0, c.T2, M, false, c.Linv, M, true, 0.0, c.B, M);
+  big_elem(s, c, 2, false);
+  gemm(s, M, M, M, 1.0, c.T1, M, false, c.Linv, M, false, 0.0, c.T2, M);
+  gemm(s, M, M, M, 1.0, c.Linv, M, true, c.T2, M, false, 0.0, c.dLdpsi2, M, c.scal + 4);
+  big_elem(s, c, 3, false);
+  hipLaunchKernelGGL(big_trace_kernel, dim3(1), dim3(CH_THREADS), 0, s, M, c.B, c.scal + 2);
+  if (ev_after_b && (e = hipEventRecord(ev_after_b, s)) != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain event: ") + hipGetErrorString(e));
+  // ---- (c) Ls = chol(S), LsInv; Kinv; Sinv; woodbury_inv                                            (:95,205-213,154)
+  big_elem(s, c, 8, false);
+  if ((st = chol_big(h, s, c.LsInv, M, c.bigD, c.bigP, c.scal + 1, c.status))) return st;
+  trtri_big(s, c.LsInv, M, c.bigD, c.T3, c.bigP);
+  gemm(s, M, M, M, 1.0, c.T3, M, true, c.T3, M, false, 0.0, c.Sinv, M);
+  gemm(s, M, M, M, 1.0, c.Linv, M, true, c.Linv, M, false, 0.0, c.Kinv, M);
+  big_elem(s, c, 4, false);
+  gemm(s, M, M, D, 1.0 / (double)D, c.Kinv_mu, D, false, c.Kinv_mu, D, true, 1.0, c.Wi, M);
+  e = hipGetLastError();
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain (blocked): ") + hipGetErrorString(e));
+  return RGP_OK;
+}
+
+static rgp_status svi_chain_post_big(rgp_handle h, const SviChain& c, hipStream_t s) {
+  const int M = c.M, D = c.D;
+  // X = psi2 Kinv ; mA = -beta Kinv X ; R = dL_dpsi2 X ; Vt = beta Kinv psi1Y^T ; Wm = Kinv_mu Vt^T
+  gemm(s, M, M, M, 1.0, c.psi2, M, false, c.Kinv, M, false, 0.0, c.T1, M);
+  gemm(s, M, M, M, 1.0, c.Kinv, M, false, c.T1, M, false, 0.0, c.mA, M, c.scal + 5);
+  gemm(s, M, M, M, 1.0, c.dLdpsi2, M, false, c.T1, M, false, 0.0, c.T2, M);
+  gemm(s, M, D, M, 1.0, c.Kinv, M, false, c.psi1Y, M, true, 0.0, c.Ybt, D, c.scal + 3);
+  gemm(s, M, M, D, 1.0, c.Kinv_mu, D, false, c.Ybt, D, true, 0.0, c.T3, M);
+  big_elem(s, c, 5, false);
+  big_elem(s, c, 6, true);
+  gemm(s, M, D, M, 1.0, c.mA, M, false, c.qU_m, D, false, 1.0, c.gqm, D);
+  if (c.gqU_W) {
+    big_elem(s, c, 7, false);
+    gemm(s, M, M, M, 1.0, c.T1, M, false, c.qU_W, M, false, 0.0, c.gqU_W, M);
+  }
+  hipLaunchKernelGGL(big_final_kernel, dim3(1), dim3(CH_THREADS), 0, s, c);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain post (blocked): ") + hipGetErrorString(e));
+  return RGP_OK;
+}
+
 size_t svi_chain_ws_doubles(int M, int D) {
-  return (size_t)18 * M * M + 6 * (size_t)M * D + 64;
+  return (size_t)18 * M * M + 6 * (size_t)M * D + 64 + (M > CH_MAX_M ? big_fact_doubles(M) + 64 : 0);
 }
 
 void svi_chain_carve(SviChain& c, WsAlloc& ws) {
@@ -531,10 +757,11 @@ void svi_chain_carve(SviChain& c, WsAlloc& ws) {
   c.gmu = ws.take<double>(md); c.Kinv_mu = ws.take<double>(md); c.Cpsi1 = ws.take<double>(md); c.Ybt = ws.take<double>(md);
   c.gqm = ws.take<double>(md);
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1);
+  if (c.M > CH_MAX_M) big_fact_carve(c.M, c.bigD, c.bigP, ws);
 }
 
 rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t stream, hipEvent_t ev_after_a, hipEvent_t ev_after_b) {
-  if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "svi chain: M > 128 needs the blocked factorisation (not in this build)");
+  if (c.M > CH_MAX_M) return svi_chain_pre_big(h, c, stream, ev_after_a, ev_after_b);
   size_t lds = ((size_t)c.M * (c.M + 1) + LDS_FACT_EXTRA) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_pre_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -552,6 +779,7 @@ rgp_status launch_svi_chain_pre(rgp_handle h, const SviChain& c, hipStream_t str
 }
 
 rgp_status launch_svi_chain_post(rgp_handle h, const SviChain& c, hipStream_t stream) {
+  if (c.M > CH_MAX_M) return svi_chain_post_big(h, c, stream);
   const size_t lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)svi_chain_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("svi chain post LDS attr: ") + hipGetErrorString(e));

@@ -374,6 +374,7 @@ struct FinalizeArgs {
   const double *dLs, *psi2;  // symmetrised dL_dpsi2 and summed psi2 (may be null)
   const double *dz1;       // [M x QP] psi1 part (may be null)
   const double *dz2;       // [QP x 128] psi2 part, transposed layout (may be null)
+  int dz2_ld;              // row stride of dz2 (0: RGP_PSI2_TEAM)
   const double *dlam1, *dlam2, *lsum1, *wsum2;    // may be null
   double dk_scale;         // weight of the K_uu backward term (1, or 1/world for the data-parallel collapsed bound)
   double psi0_coef;        // sum_n dL_dpsi0[n]  (d psi0/d variance = 1)
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, doub
     if (q < Q) {
       double dz = -a.lam[q] * s1;
       if (a.dz1) dz += a.dz1[m * QP + q];
-      if (a.dz2) dz += a.dz2[q * RGP_PSI2_TEAM + m];
+      if (a.dz2) dz += a.dz2[(size_t)q * (a.dz2_ld ? a.dz2_ld : RGP_PSI2_TEAM) + m];
       a.gZ[m * Q + q] = dz;
     }
     dlrow[m * QP + q] = (q < Q) ? -0.5 * s2 : 0.0;
@@ -638,6 +639,9 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.zt.c = ws.take<double>(QP); L.zt.lam = ws.take<double>(QP); L.zt.Zc = ws.take<double>((size_t)M * QP); L.zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.zt.zd = ws.take<double>((size_t)M * M); L.zt.Kuu = ws.take<double>((size_t)M * M);
   if (ch) svi_chain_carve(*ch, ws);        // before anything sized by N: a chain-only prepare fixes these addresses
+  // dLs is written by the chain's second kernel (chain-only prepare) and read by the psi2 pass and the finalisation of a
+  // layer step that may re-carve the slot with a smaller N: it must sit in front of every N-sized buffer as well
+  L.psi2 = ws.take<double>((size_t)M * M); L.dLs = ws.take<double>((size_t)M * M);
   L.rt.N = N; L.rt.QP = QP;
   L.rt.Xmu = ws.take<double>(nq); L.rt.d2 = ws.take<double>(nq); L.rt.e1 = ws.take<double>(nq); L.rt.em = ws.take<double>(nq);
   L.rt.g0 = ws.take<double>(N); L.rt.g1 = ws.take<double>(N);
@@ -645,7 +649,6 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   L.gmu = ws.take<double>(nq); L.gS = ws.take<double>(nq);
   L.Ym = ws.take<double>(nd); L.Yv = ws.take<double>(nd); L.dYm = ws.take<double>(nd);
   L.p2_part = ws.take<double>((size_t)L.nblk2 * tri); L.p2_tri = ws.take<double>(tri);
-  L.psi2 = ws.take<double>((size_t)M * M); L.dLs = ws.take<double>((size_t)M * M);
   L.dz1_part = ws.take<double>((size_t)L.nblk1 * M * QP); L.dz1 = ws.take<double>((size_t)M * QP);
   L.dz2_part = ws.take<double>((size_t)2 * L.nblk2 * QP * RGP_PSI2_TEAM); L.dz2 = ws.take<double>((size_t)QP * RGP_PSI2_TEAM);
   L.dlam1_part = ws.take<double>((size_t)PSI1_ROWS_MAXBLK * QP); L.dlam1 = ws.take<double>(QP);     // PSI1_ROWS_MAXBLK >= NBLK1
@@ -665,16 +668,20 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
   return ws.off;
 }
 
+static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D);
 extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
+  if (M > RGP_MAX_M) return big_workspace_bytes(N, M, Q, D);
   rgp_ctx tmp;
   LayerWs L;
   SviChain ch{}; ch.M = M; ch.D = D > 0 ? D : 1;
   return (int64_t)carve_layer(&tmp, nullptr, N, M, Q, D, 4096, L, &ch);
 }
 
+static inline bool rgp_is_big(int M) { return M > RGP_MAX_M; }
+
 static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
-  if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is not supported by this build");
+  if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is supported by the SVI bound only (collapsed bound: M <= 128)");
   if (rgp_qp(Q) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
   return RGP_OK;
 }
@@ -685,13 +692,15 @@ static rgp_status last_launch(rgp_handle h, const char* what) {
   return RGP_OK;
 }
 
+#include "rgp_big_impl.h"
+
 // ==================================================================================================================
 // unit entry points
 // ==================================================================================================================
 extern "C" rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,
                               double jitter, double* Kuu) {
   if (!h) return RGP_ERR_BAD_ARG;
-  rgp_status st = check_geometry(h, 1, M, Q);
+  rgp_status st = rgp_is_big(M) ? big_check(h, 1, M, Q) : check_geometry(h, 1, M, Q);
   if (st) return st;
   LayerWs L;
   const size_t need = carve_layer(h, nullptr, 1, M, Q, 1, 1, L, nullptr);
@@ -706,6 +715,7 @@ extern "C" rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, con
                                       const double* Z, const double* variance, const double* inv_l, double* psi1,
                                       double* psi2) {
   if (!h) return RGP_ERR_BAD_ARG;
+  if (rgp_is_big(M)) return big_psi_forward(h, N, M, Q, mu, S, Z, variance, inv_l, psi1, psi2);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;
   LayerWs L;
@@ -732,6 +742,8 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
                                        double dL_dpsi0_sum, const double* dL_dpsi1, const double* dL_dpsi2, double* dvar,
                                        double* dinv_l, double* dZ, double* dmu, double* dS) {
   if (!h) return RGP_ERR_BAD_ARG;
+  if (rgp_is_big(M))
+    return big_psi_backward(h, N, M, Q, mu, S, Z, variance, inv_l, dL_dpsi0_sum, dL_dpsi1, dL_dpsi2, dvar, dinv_l, dZ, dmu, dS);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;
   LayerWs L;
@@ -1101,6 +1113,7 @@ extern "C" rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, co
 extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
   if (!h || !in) return RGP_ERR_BAD_ARG;
   if (in->mode != RGP_MODE_SVI) return RGP_OK;
+  if (rgp_is_big(in->M)) return RGP_OK;            // the blocked path runs whole layer steps on the main stream
   rgp_status st = svi_check_args(h, in);
   if (st) return st;
   const int flags = in->reserved & (RGP_PREPARE_CHAIN_ONLY | RGP_PREPARE_ROWS_ONLY);
@@ -1153,6 +1166,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (!h || !in || !out) return RGP_ERR_BAD_ARG;
   if (in->mode == RGP_MODE_VARDTC) return vardtc_layer_step(h, in, out);
   if (in->mode != RGP_MODE_SVI) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: unknown mode");
+  if (rgp_is_big(in->M)) return big_svi_layer_step(h, in, out);
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;

@@ -6,6 +6,33 @@
 #define RGP_MAX_M 128
 #define RGP_MAX_QP 64
 
+// exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
+// n = rint(x * 256/ln2) = 256 k + j, r = x - n ln2/256 (|r| <= ln2/512) and q the degree-4 Taylor polynomial of expm1 (next
+// term r^5/120 < 4e-17).  T[j] = 2^(j/256) is a 256-entry LDS table (2 KB).  14 VALU instructions and one LDS read instead of
+// the ~36 (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp
+// (the rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register
+// sources: the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
+#define PSI2_EXP_TAB 256
+static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
+  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
+  const double t = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);          // 256/ln2; integer n in the low mantissa bits
+  const int n = __double2loint(t);
+  const double nf = t - 0x1.8p52;
+  double r = fma(nf, -0x1.62e42fee00000p-9, x);                     // ln2/256 split: the high part has 32 significant bits
+  r = fma(nf, -0x1.a39ef35793c76p-41, r);
+  const double tj = T[n & (PSI2_EXP_TAB - 1)];
+  double q = fma_rrr(r, 0x1.5555555555555p-5, 0x1.5555555555555p-3);       // 1/24, 1/6
+  q = fma_rrr(q, r, 0.5);
+  q = fma_rrr(q, r, 1.0);
+  q = q * r;
+  return ldexp(fma(tj, q, tj), n >> 8);
+}
+
 // Z-derived, data-independent quantities of one layer.
 struct ZTerms {
   int M, Q, QP;

@@ -16,33 +16,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-// exp(x) for the psi2 sweep (x <= ~700, any negative x including -inf): 2^k * T[j] * (1 + q(r)) with
-// n = rint(x * 256/ln2) = 256 k + j, r = x - n ln2/256 (|r| <= ln2/512) and q the degree-4 Taylor polynomial of expm1 (next
-// term r^5/120 < 4e-17).  T[j] = 2^(j/256) is a 256-entry LDS table (2 KB).  14 VALU instructions and one LDS read instead of
-// the ~36 (27 fp64 + 9 register copies of polynomial constants) the library exp compiled to in the sweep; error <= 1 ulp
-// (the rounding of T[j] plus one fused multiply-add).  The Horner steps are written as v_fma_f64 with three register
-// sources: the compiler's own choice (copy the constant, then v_fmac) doubled their issue cost.
-#define PSI2_EXP_TAB 256
-static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
-  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
-  const double t = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);          // 256/ln2; integer n in the low mantissa bits
-  const int n = __double2loint(t);
-  const double nf = t - 0x1.8p52;
-  double r = fma(nf, -0x1.62e42fee00000p-9, x);                     // ln2/256 split: the high part has 32 significant bits
-  r = fma(nf, -0x1.a39ef35793c76p-41, r);
-  const double tj = T[n & (PSI2_EXP_TAB - 1)];
-  double q = fma_rrr(r, 0x1.5555555555555p-5, 0x1.5555555555555p-3);       // 1/24, 1/6
-  q = fma_rrr(q, r, 0.5);
-  q = fma_rrr(q, r, 1.0);
-  q = q * r;
-  return ldexp(fma(tj, q, tj), n >> 8);
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Z-derived terms
 // ------------------------------------------------------------------------------------------------------------------
@@ -75,15 +48,16 @@ __global__ void __launch_bounds__(256) prep_z_kernel(int M, int Q, int QP, const
 __global__ void __launch_bounds__(128) kuu_rows_kernel(int M, int Q, int QP, const double* __restrict__ variance,
                                                         const double* __restrict__ Zc, const double* __restrict__ lam,
                                                         double jitter, double* __restrict__ zd, double* __restrict__ Kuu) {
-  const int a = blockIdx.x, b = threadIdx.x;
-  if (b >= M) return;
-  double r = 0.0;
-  for (int q = 0; q < Q; ++q) {
-    const double d = Zc[a * QP + q] - Zc[b * QP + q];
-    r += lam[q] * d * d;
+  const int a = blockIdx.x;
+  for (int b = threadIdx.x; b < M; b += blockDim.x) {
+    double r = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      const double d = Zc[(size_t)a * QP + q] - Zc[(size_t)b * QP + q];
+      r += lam[q] * d * d;
+    }
+    zd[(size_t)a * M + b] = -0.25 * r;
+    Kuu[(size_t)a * M + b] = variance[0] * exp(-0.5 * r) + (a == b ? jitter : 0.0);
   }
-  zd[a * M + b] = -0.25 * r;
-  Kuu[a * M + b] = variance[0] * exp(-0.5 * r) + (a == b ? jitter : 0.0);
 }
 
 void launch_prep_z(hipStream_t s, int M, int Q, int QP, const double* Z, const double* variance, const double* inv_l,

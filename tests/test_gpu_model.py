@@ -17,12 +17,13 @@ def make_data(n_seq, T, u_dim=2, y_dim=3, seed=0, ragged=False):
 
 
 def build_pair(n_seq=3, T=14, wins=(0, 3, 3), nDims=(3, 2, 3), M=4, U_win=2, seed=0, ragged=False, n_total=None,
-               u_dim=2, y_dim=3, inference='svi'):
+               u_dim=2, y_dim=3, inference='svi', fast_psi=False, chunk=16):
     from oracle import model as om
     from rgp_amd.model import DeepAutoreg
     U, Y = make_data(n_seq, T, u_dim, y_dim, seed, ragged)
     o = om.DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
-                       inference_method=inference, n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=False)
+                       inference_method=inference, n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=fast_psi,
+                       chunk=chunk)
     rng = np.random.default_rng(seed + 2)
     for i in o.order:
         p = o.P[i]
@@ -348,7 +349,7 @@ def test_unsupported_sizes_fail_loudly():
     from rgp_amd._lib import RgpError
     from rgp_amd.model import DeepAutoreg
     U, Y = make_data(1, 40, u_dim=1, y_dim=1)
-    m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=129, inference_method='svi')   # M > 128
+    m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=1025, inference_method='svi')   # M > 1024
     with pytest.raises(RgpError):
         m.evaluate()
     m2 = DeepAutoreg([0, 40], Y[:1], U=U[:1], U_win=30, nDims=[1, 1], num_inducing=4, inference_method='svi')   # Q = 70 > 64
@@ -405,6 +406,23 @@ def test_pipelined_svi_steps_equal_plain_steps():
     assert abs(float(ea_l[-1].item()) - eb_l[-1]) <= 1e-11 * abs(eb_l[-1])
     a.handle.sync(); b.handle.sync()
     assert float((a.param_array - b.param_array).abs().max()) <= 1e-11 * float(b.param_array.abs().max())
+
+
+def test_pipelined_ragged_smaller_minibatch():
+    """Pipelined steps whose minibatch has FEWER rows than the one the early M x M chains were sized for (ragged sequences,
+    a short trailing minibatch): the chain-only prepare and the layer step carve the workspace with different N, and every
+    buffer the chain writes must sit at an N-independent address.  Parameters after the steps must equal the unpipelined
+    ones (they depend on every gradient, not only on the ELBO)."""
+    _, a = build_pair(n_seq=5, T=30, M=6, seed=11, n_total=5, ragged=True)
+    _, b = build_pair(n_seq=5, T=30, M=6, seed=11, n_total=5, ragged=True)
+    b.pipeline = False
+    mbs = [slice(3, 5), slice(0, 2), slice(2, 3), slice(3, 5), slice(1, 2), [4, 2], [0]]
+    for k, mb in enumerate(mbs):
+        ea = float(a.svi_step(mb, lr=2e-2).item())
+        eb = float(b.svi_step(mb, lr=2e-2).item())
+        assert abs(ea - eb) <= 1e-11 * abs(eb), (k, ea, eb)
+        a.handle.sync(); b.handle.sync()
+        assert float((a.param_array - b.param_array).abs().max()) <= 1e-11 * float(b.param_array.abs().max()), k
 
 
 def test_prefetched_next_minibatch_equals_plain_steps():
