@@ -240,18 +240,20 @@ class DeepAutoreg(object):
             # ---- a10 + a12: dL/dq(X) scattered back onto the latents (layers.py:1433-1458) ----
             off = 0
             Qx = X_win * self.nDims[i] if X_win > 0 else 0
+            # reference_scatter: the literal per-row Python loop of the reference (CPU-baseline timing of its structure)
+            sc = scatter_reference_loop if getattr(self, 'reference_scatter', False) else _scatter
             for s in seqs:
                 n_s = self._own_len(i, s) - X_win
                 dm, dv = pg['dmu'][off:off + n_s], pg['dS'][off:off + n_s]
                 if X_win > 0:
-                    _scatter(gXm[i][s], dm[:, :Qx], 0, X_win)
-                    _scatter(gXv[i][s], dv[:, :Qx], 0, X_win)
+                    sc(gXm[i][s], dm[:, :Qx], 0, X_win)
+                    sc(gXv[i][s], dv[:, :Qx], 0, X_win)
                 if i < self.nLayers - 1:
                     uw = self.wins[i + 1]
                     T_u = self.Xmean[i + 1][s].shape[0]
                     u_off = T_u - n_s - uw + 1                            # layers.py:1439
-                    _scatter(gXm[i + 1][s], dm[:, Qx:], u_off, uw)
-                    _scatter(gXv[i + 1][s], dv[:, Qx:], u_off, uw)
+                    sc(gXm[i + 1][s], dm[:, Qx:], u_off, uw)
+                    sc(gXv[i + 1][s], dv[:, Qx:], u_off, uw)
                 off += n_s
         self.last_elbo = elbo
         if not want_grads:

@@ -535,14 +535,17 @@ __global__ void __launch_bounds__(256) big_rowgrad_kernel(int64_t N, int Q, int 
 
 // backward pass + its reductions: row gradients into gmu / gS, dz2 [QP][Mld], dlam2 [QP], wsum2 [1]
 static rgp_status launch_big_psi2_bwd(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, const ZTerms& zt,
-                                      const RowTerms& rt, const double* dLs, const double* H, BigWs& L, int accumulate) {
+                                      const RowTerms& rt, const double* dLs, const double* H, BigWs& L, int accumulate,
+                                      bool profile = false) {
   hipError_t e = hipSuccess;
+  if (profile) prof_begin(h, (double)N * M * M * Q);        // rgp_get_profile times the sweep kernel alone
   switch (zt.QP) {
 #define B2B(qp) case qp: e = big_bwd_launch<qp>(s, p, N, M, zt, rt, dLs, H, L.RP, L.dz2_part); break;
     B2B(8) B2B(16) B2B(20) B2B(24) B2B(32) B2B(40) B2B(48) B2B(56) B2B(64)
 #undef B2B
     default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (blocked): unsupported padded Q");
   }
+  if (profile) prof_end(h);
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 backward (blocked): ") + hipGetErrorString(e));
   hipLaunchKernelGGL(big_rowgrad_kernel, dim3(p.rows_blk), dim3(256), 0, s, N, Q, p.QP, p.nI, L.RP, rt.Xmu, rt.d2, zt.lam, L.gmu,
                      L.gS, accumulate, L.dlam2_part, L.wsum2_part);
@@ -732,10 +735,8 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
 
   // psi2: forward sum, then backward with the symmetrised dL/dpsi2 of the chain
-  prof_begin(h, (double)N * M * M * Q);
   st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
-  if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
-  prof_end(h);
+  if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1, true);
   if (st) return st;
 
   // latent gradients

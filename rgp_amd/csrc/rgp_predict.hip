@@ -144,6 +144,139 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_kernel(FreerunArgs a, cons
   }
 }
 
+// M > 128 (up to FRB_MAX_M): thread = inducing row m (blocks of 512 rows when M > 512), every thread sweeps all m' of its part;
+// for M <= 256 the 512 threads split the m' sweep into parts.  z[m,:] is re-read per step (L2 resident) instead of held in
+// registers; same arithmetic as freerun_kernel.
+#define FRB_MAX_M 1024
+template <int QP>
+__global__ void __launch_bounds__(FR_THREADS) freerun_big_kernel(FreerunArgs a, const double* __restrict__ Zc,
+                                                                  const double* __restrict__ wv_g,
+                                                                  const double* __restrict__ winv_g) {
+  __shared__ double d2s[QP], dmls[QP], e1s[QP], mus[QP];
+  __shared__ double hbuf[FRB_MAX_M], p1buf[FRB_MAX_M];
+  __shared__ double red[8][FR_DC + 2];
+  __shared__ double scratch[16];
+  const int M = a.M, Q = a.Q, D = a.D;
+  const int t = threadIdx.x;
+  const int ru = (M + 63) / 64 * 64;                                   // lanes per part (whole waves)
+  const int parts = (ru <= FR_THREADS / 2) ? FR_THREADS / ru : 1;
+  const int part = __builtin_amdgcn_readfirstlane(parts > 1 ? t / ru : 0);
+  const int tl = parts > 1 ? t - part * ru : t;
+  const bool in_part = part < parts;
+  const int Mq = (M + parts - 1) / parts;
+  const int mp0 = in_part ? part * Mq : 0, mp1 = in_part ? ((mp0 + Mq < M) ? mp0 + Mq : M) : 0;
+  const int mstep = parts > 1 ? M : FR_THREADS;                        // parts > 1: one pass (m = tl); else blocks of 512 rows
+  const int seq = blockIdx.x;
+  const int Qx = a.X_win * a.X_dim;
+  const int64_t T_out = a.X_win + a.steps;
+  double* Xm = a.X_mean + (size_t)seq * T_out * a.X_dim;
+  double* Xv = a.X_var + (size_t)seq * T_out * a.X_dim;
+  const double* Um = a.U_mean ? a.U_mean + ((size_t)seq * a.u_rows + a.u_skip) * a.U_dim : nullptr;
+  const double* Uv = a.U_var ? a.U_var + ((size_t)seq * a.u_rows + a.u_skip) * a.U_dim : nullptr;
+  const double var = a.variance[0], logvar = log(var);
+  for (int i = t; i < Qx; i += FR_THREADS) {
+    Xm[i] = a.init_mean ? a.init_mean[(size_t)seq * Qx + i] : 0.0;
+    Xv[i] = a.init_var ? a.init_var[(size_t)seq * Qx + i] : 1.0;
+  }
+  __syncthreads();
+
+  for (int n = 0; n < a.steps; ++n) {
+    double sl2 = 0.0, sl1 = 0.0, sdm = 0.0;
+    if (t < QP) {
+      double mu = 0.0, d2 = 0.0, e1 = 0.0, dml = 0.0;
+      if (t < Q) {
+        double m, S;
+        if (t < Qx) { m = Xm[(size_t)n * a.X_dim + t]; S = Xv[(size_t)n * a.X_dim + t]; }
+        else { const int64_t i = (int64_t)n * a.U_dim + (t - Qx); m = Um[i]; S = Uv ? Uv[i] : a.u_var_const; }
+        const double lam = a.lam[t];
+        mu = m - a.c[t];
+        const double t2 = 1.0 + 2.0 * S * lam, t1 = 1.0 + S * lam;
+        d2 = lam / t2; e1 = lam / t1; dml = -2.0 * S * lam * d2;
+        sl2 = log(t2); sl1 = log(t1); sdm = d2 * mu * mu;
+      }
+      mus[t] = mu; d2s[t] = d2; e1s[t] = e1; dmls[t] = dml;
+    }
+    sl2 = block_sum(sl2, scratch); sl1 = block_sum(sl1, scratch); sdm = block_sum(sdm, scratch);
+    const double g0 = 2.0 * logvar - 0.5 * sl2 - sdm, g1 = logvar - 0.5 * sl1;
+    __syncthreads();
+    // ---- per inducing row: h, psi1 ----
+    for (int m = t; m < M; m += FR_THREADS) {
+      const double* __restrict__ zr = Zc + (size_t)m * QP;
+      double h = 0.0, e = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const double z = zr[q];
+        h += z * d2s[q] * (mus[q] - 0.25 * z) - 0.25 * a.lam[q] * z * z;
+        const double df = mus[q] - z;
+        e += e1s[q] * df * df;
+      }
+      hbuf[m] = h;
+      p1buf[m] = exp(g1 - 0.5 * e);
+    }
+    __syncthreads();
+    for (int d0 = 0; d0 < D; d0 += FR_DC) {
+      const int dc = (D - d0 < FR_DC) ? D - d0 : FR_DC;
+      double acc[FR_DC];
+#pragma unroll
+      for (int d = 0; d < FR_DC; ++d) acc[d] = 0.0;
+      double trc = 0.0;
+      for (int mb = 0; mb < M; mb += mstep) {
+        const int m = mb + tl;
+        const bool act = in_part && tl < mstep && m < M;
+        const int tm = act ? m : M - 1;
+        const double* __restrict__ zr = Zc + (size_t)tm * QP;
+        double dzl[QP], wvm[FR_DC];
+#pragma unroll
+        for (int q = 0; q < QP; ++q) dzl[q] = zr[q] * dmls[q];
+#pragma unroll
+        for (int d = 0; d < FR_DC; ++d) wvm[d] = (d < dc) ? wv_g[(size_t)tm * D + d0 + d] : 0.0;
+        const double base = act ? (g0 + hbuf[tm]) : -INFINITY;
+        const double p1 = act ? p1buf[tm] : 0.0;
+        for (int mp = mp0; mp < mp1; ++mp) {
+          const double* __restrict__ zs = Zc + (size_t)mp * QP;
+          const double* __restrict__ ws = wv_g + (size_t)mp * D + d0;
+          double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < QP; q += 2) { c0 += dzl[q] * zs[q]; c1 += dzl[q + 1] * zs[q + 1]; }
+          const double p = exp((base + hbuf[mp]) - 0.5 * (c0 + c1));
+          const double tt = p - p1 * p1buf[mp];
+          trc += winv_g[(size_t)mp * M + tm] * p;
+#pragma unroll
+          for (int d = 0; d < FR_DC; ++d)
+            if (d < dc) acc[d] += tt * wvm[d] * ws[d];
+        }
+      }
+      const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+      for (int d = 0; d < FR_DC; ++d) {
+        const double sv = wave_sum(acc[d]);
+        if (lane == 0) red[wave][d] = sv;
+      }
+      {
+        const double sv = wave_sum(trc);
+        if (lane == 0) red[wave][FR_DC] = sv;
+      }
+      __syncthreads();
+      if (t < dc) {
+        double qf = 0.0, tr_ = 0.0, mean = 0.0;
+        for (int w = 0; w < 8; ++w) { qf += red[w][t]; tr_ += red[w][FR_DC]; }
+        for (int m = 0; m < M; ++m) mean += p1buf[m] * wv_g[(size_t)m * D + d0 + t];
+        double v = qf + var - tr_;
+        v = fmax(v, 1e-15);                               // GPy _raw_predict clip
+        if (v <= 0.0) v = 1e-10;                          // layers.py:1570
+        Xm[(size_t)(a.X_win + n) * a.X_dim + d0 + t] = mean;
+        Xv[(size_t)(a.X_win + n) * a.X_dim + d0 + t] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int QP>
+static void freerun_big_launch(hipStream_t s, const FreerunArgs& a) {
+  hipLaunchKernelGGL((freerun_big_kernel<QP>), dim3(a.n_seq), dim3(FR_THREADS), 0, s, a, a.Zc, a.wv, a.winv);
+}
+
 template <int QP>
 static void freerun_launch(hipStream_t s, const FreerunArgs& a) {
   hipLaunchKernelGGL((freerun_kernel<QP>), dim3(a.n_seq), dim3(FR_THREADS), 0, s, a, a.Zc, a.wv, a.winv);
@@ -157,8 +290,9 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   if (!h) return RGP_ERR_BAD_ARG;
   const int X_dim = D;
   const int Q = X_win * X_dim + U_win * U_dim;
-  if (M > RGP_MAX_M || rgp_qp(Q) > RGP_MAX_QP || Q <= 0)
-    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 128 and 0 < Q <= 64 in this build");
+  if (M > FRB_MAX_M || rgp_qp(Q) > RGP_MAX_QP || Q <= 0)
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 1024 and 0 < Q <= 64 in this build");
+  const bool big = M > RGP_MAX_M;
   if (U_win > 0 && (!U_mean || u_rows - u_skip < steps + U_win - 1))
     return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: not enough input rows for the requested steps");
   const int QP = rgp_qp(Q);
@@ -177,6 +311,14 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   a.u_rows = u_rows; a.u_skip = u_skip; a.Zc = zt.Zc; a.lam = zt.lam; a.c = zt.c; a.variance = variance; a.winv = woodbury_inv;
   a.wv = woodbury_vector; a.init_mean = init_mean; a.init_var = init_var; a.U_mean = U_mean; a.U_var = U_var;
   a.u_var_const = u_var_const; a.X_mean = X_mean; a.X_var = X_var;
+  if (big) {
+    switch (QP) {
+#define FRB(qp) case qp: freerun_big_launch<qp>(h->stream, a); break;
+      FRB(8) FRB(16) FRB(20) FRB(24) FRB(32) FRB(40) FRB(48) FRB(56) FRB(64)
+#undef FRB
+      default: return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: unsupported padded Q");
+    }
+  } else
   switch (QP) {
     case 8: freerun_launch<8>(h->stream, a); break;
     case 16: freerun_launch<16>(h->stream, a); break;

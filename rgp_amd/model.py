@@ -229,6 +229,10 @@ class DeepAutoreg(object):
         # every other way of changing parameters goes through _flush_pipeline first.  Code that writes param_array directly
         # between svi_step calls must call params_changed().
         self.pipeline = os.environ.get('RGP_NO_PIPELINE') is None
+        # data-parallel steps: False = each layer's global gradients are all-reduced as soon as they exist (pipelined steps,
+        # one collective per layer); True = ONE all-reduce of the whole [global gradients | ELBO] bucket per step, the exchange
+        # the reference's dead stub stood for (svi_vardtc.py:65-67)
+        self.single_bucket = False
         self._chain_ready = False
         self._chain_n = None
         self._post_stream = None
@@ -573,7 +577,8 @@ class DeepAutoreg(object):
         if self._adam is None:
             self._init_adam()
         ad, h = self._adam, self.handle
-        pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate
+        pipelined = update and self.svi and self.pipeline and len(self.layers) <= 3 and type(self).evaluate is DeepAutoreg.evaluate \
+            and not (allreduce is not None and self.single_bucket)
         if pipelined:
             try:
                 elbo = self._svi_step_pipelined(seqs, lr, allreduce, qU_ratio, lazy_elbo, next_seqs)

@@ -179,3 +179,18 @@ def test_big_workspace_bytes_and_limits():
     m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=129, inference_method=None)    # collapsed bound: M <= 128
     with pytest.raises(RgpError):
         m.evaluate()
+
+
+@pytest.mark.parametrize('M', [129, 600])
+def test_big_freerun_matches_oracle(M):
+    """Moment-matching free-run (layers.py:1551-1571) with M > 128: the m' sweep split into parts (M <= 256) and inducing rows
+    in blocks of 512 (M > 512)."""
+    from test_gpu_model import compare
+    o, g = _pair(n_seq=2, T=16, M=M)
+    compare(o, g, rtol=1e-8)
+    U = np.random.default_rng(8).standard_normal((12, 2))
+    want, got = o.freerun(U), g.freerun(U)
+    g.handle.sync()
+    for (wm, wv), (gm, gv) in zip(want, got):
+        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-6, atol=1e-10)

@@ -34,7 +34,7 @@ def _globals0():
     return _model(Y, U).param_array[:_model(Y, U).n_global].clone()
 
 
-def _worker(rank, world, port, out_path, lazy):
+def _worker(rank, world, port, out_path, lazy, single_bucket=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
@@ -46,7 +46,11 @@ def _worker(rank, world, port, out_path, lazy):
     m = _model(Y[a:b], U[a:b])
     m.param_array[:m.n_global].copy_(full.param_array[:full.n_global])
     m.params_changed()
-    allreduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    def allreduce(t):              # gloo moves host tensors only: stage the device bucket through the host
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        t.copy_(c)
+    m.single_bucket = single_bucket
     elbos = []
     for k in range(STEPS):
         e = m.svi_step(slice(0, b - a), lr=1e-2, allreduce=allreduce, qU_ratio=float(NTOT) / NTOT / world, lazy_elbo=lazy)
@@ -61,10 +65,12 @@ def _worker(rank, world, port, out_path, lazy):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('lazy', [False, True])
-def test_two_ranks_track_the_single_process_run(tmp_path, lazy):
+@pytest.mark.parametrize('lazy,single_bucket', [(False, False), (True, False), (False, True)])
+def test_two_ranks_track_the_single_process_run(tmp_path, lazy, single_bucket):
+    """Per-layer collectives inside the pipelined step (eager and lazy ELBO) and ONE bucket per step give the same
+    trajectory as the single-process run on the union minibatch."""
     out = str(tmp_path / 'dp.npz')
-    mp.spawn(_worker, args=(2, _free_port(), out, lazy), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, lazy, single_bucket), nprocs=2, join=True)
     got = np.load(out)
     U, Y = make_data(NTOT, T, seed=0)
     m = _model(Y, U)
