@@ -20,6 +20,16 @@
 #include "rgp_gemm.h"
 
 #define RGP_BIG_MAX_M 1024
+// forward psi2 kernel: column groups per wave task, rows per tile, inducing columns per lane (padded Q <= 48)
+#ifndef BF_G
+#define BF_G 8
+#endif
+#ifndef BF_RT
+#define BF_RT 16
+#endif
+#ifndef BF_NP
+#define BF_NP 2           // inducing columns per lane for padded Q <= 48 (1: half the registers, four waves per SIMD)
+#endif
 
 struct BigPlan {
   int QP, W, Mld, Mp;
@@ -44,14 +54,16 @@ static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
   const int64_t maxg = (N + p.NT - 1) / p.NT;
   if (g > maxg) g = maxg;
   p.bwd_grid = (int)(g < 1 ? 1 : g);
-  p.NP = p.QP <= 48 ? 2 : 1;
-  const int nIB = (M + 63) / 64, nG = (M + p.NP - 1) / p.NP;
+  p.NP = p.QP <= 48 ? BF_NP : 1;
+  const int CG = p.NP * BF_G;                                          // inducing columns per wave task
+  const int nIB = (M + 63) / 64, nSG = (M + CG - 1) / CG;
   int tasks = 0;
-  for (int ib = 0; ib < nIB; ++ib) tasks += nG - (64 * ib) / p.NP;
+  for (int ib = 0; ib < nIB; ++ib) tasks += nSG - (64 * ib) / CG;
   p.fwd_tasks = tasks;
-  int64_t ch = ((int64_t)32 * h->num_cu + tasks - 1) / tasks;        // ~4 rounds of 8 waves per CU
-  if (ch > 64) ch = 64;
-  if (ch > N) ch = N;
+  const int fblocks = (tasks + 7) / 8;
+  int64_t ch = ((int64_t)4 * h->num_cu + fblocks - 1) / fblocks;       // ~4 rounds of one 512-thread workgroup per CU
+  if (ch > 128) ch = 128;
+  if (ch > (N + 15) / 16) ch = (N + 15) / 16;
   p.fwd_chunks = (int)(ch < 1 ? 1 : ch);
   int64_t sk = (N + 511) / 512;
   p.sk = (int)(sk < 1 ? 1 : (sk > 256 ? 256 : sk));
@@ -241,65 +253,120 @@ __global__ void __launch_bounds__(256) big_rows1_kernel(int64_t N, int Q, int QP
 
 // ------------------------------------------------------------------------------------------------------------------
 // psi2 forward.  psi2[m,m'] = sum_n exp( g0[n] + H[n,m] + H[n,m'] + sum_q dm[n,q] z[m,q] z[m',q] ).
-// Wave task = (block of 64 inducing rows, group of NP inducing columns that reaches the block's diagonal); the products
-// zz[q] = z[m,q] z[m',q] stay in registers for the whole pass, dm[n,:], g0[n] and H[n,m'] are scalar operands.
+// Wave task = (block of 64 inducing rows m = lanes, BF_G groups of NP inducing columns m' that reach the block's diagonal).
+// The products zz[q] = z[m,q] z[m',q] of the group in work sit in registers, dm[n,:], g0[n] and H[n,m'] are scalar operands,
+// and psi2[m,m'] accumulates in a register: no LDS, no atomics, fixed order.
+// The data rows are walked in tiles of BF_RT rows, and each tile is swept once per column group before the wave moves on:
+// the tile's scalar operands (5 KB) are then served by the scalar cache for all but the first sweep; streaming every row
+// once per group from L2/HBM left the VALU idle two thirds of the time (one row = 80 multiply-adds per 330 B of scalar loads
+// that cannot be double-buffered in ~100 SGPRs).  The eight waves of a workgroup share the tile (barrier per tile).
 // part: [chunk][M][M]; entry (m, m') is written only for m' >= 64 floor(m/64) (big_psi2_unpack_kernel reads m' >= m).
 // ------------------------------------------------------------------------------------------------------------------
 template <int QP, int NP>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, (NP == 1 && QP <= 48) ? 4 : 2)
 big_psi2_fwd_kernel(const int64_t N, const int M, const int ntasks, const double* __restrict__ Zc, const double* __restrict__ dm,
-                    const double* __restrict__ H, const double* __restrict__ g0, double* __restrict__ part) {
-  __shared__ double etab[PSI2_EXP_TAB];
+                    const double* __restrict__ H, const double* __restrict__ g0, double* part) {
+  extern __shared__ double lds[];
+  double* etab = lds;                                           // [256]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int CG4 = 16;                                       // row stride of hx (>= columns per task)
+  static_assert(NP * BF_G <= CG4 && BF_RT % 4 == 0, "tile staging layout");
+  double* hl = lds + PSI2_EXP_TAB + (size_t)wave * BF_RT * (64 + CG4);      // [BF_RT][64], private to the wave
+  double* hx = hl + BF_RT * 64;                                              // [BF_RT][CG4]
   if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
-  __syncthreads();
-  int task = (int)blockIdx.x * 4 + wave;
-  if (task >= ntasks) return;                                   // no barrier below
-  const int nIB = (M + 63) / 64, nG = (M + NP - 1) / NP;
+  int task = (int)blockIdx.x * 8 + wave;
+  const bool has_task = task < ntasks;
+  constexpr int CG = NP * BF_G;                                 // inducing columns per task
+  const int nIB = (M + 63) / 64, nSG = (M + CG - 1) / CG;
   int ib = 0;
-  for (; ib < nIB; ++ib) {
-    const int cnt = nG - (64 * ib) / NP;
+  for (; ib < nIB - 1; ++ib) {
+    const int cnt = nSG - (64 * ib) / CG;
     if (task < cnt) break;
     task -= cnt;
   }
-  const int grp = (64 * ib) / NP + task;                        // wave-uniform
+  const int col_base = ((64 * ib) / CG + task) * CG;            // wave-uniform
   const int m = 64 * ib + lane;
-  const bool act = m < M;
-  const int mc = act ? m : M - 1;
-  int mp[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) mp[p] = (NP * grp + p < M) ? NP * grp + p : M - 1;
-  double zz[NP][QP], acc[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    acc[p] = 0.0;
-#pragma unroll
-    for (int q = 0; q < QP; ++q) zz[p][q] = Zc[(size_t)mc * QP + q] * Zc[(size_t)mp[p] * QP + q];
-  }
+  const bool act = has_task && m < M;
+  const int mc = m < M ? m : M - 1;
   const int64_t per = (N + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = (int64_t)blockIdx.y * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
-  double hm = (r0 < r1) ? H[r0 * M + mc] : 0.0;
-  for (int64_t n = r0; n < r1; ++n) {
-    const double hcur = hm;
-    hm = H[((n + 1 < r1) ? n + 1 : n) * M + mc];                // next row's value lands under this row's arithmetic
-    const double* __restrict__ dn = dm + n * QP;                // wave-uniform: scalar loads
-    const double gn = g0[n];
+  double* __restrict__ prow = part + ((size_t)blockIdx.y * M + mc) * M;
+  double acc[BF_G][NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      double c0 = hcur + (gn + H[n * M + mp[p]]), c1 = 0.0;
+  for (int g = 0; g < BF_G; ++g)
 #pragma unroll
-      for (int q = 0; q < QP; q += 2) {
-        c0 += zz[p][q] * dn[q];
-        c1 += zz[p][q + 1] * dn[q + 1];
+    for (int p = 0; p < NP; ++p) acc[g][p] = 0.0;
+  for (int64_t rt = r0; rt < r1; rt += BF_RT) {
+    __syncthreads();                                            // the workgroup's waves stay on one tile (and etab is ready)
+    if (!has_task) continue;
+    const int64_t re = (rt + BF_RT < r1) ? rt + BF_RT : r1;
+    // Everything of the tile that is not the dm rows goes through a wave-private LDS strip, loaded once per tile with all
+    // loads in flight together: hl[r][lane] = g0[n] + H[n, m] (own inducing row) and hx[r][c] = H[n, col_base + c] (the task's
+    // CG inducing columns, read back as broadcasts).  As scalar loads the H[n, m'] values took one 64-byte line per 16 bytes
+    // used and, with eight waves per workgroup, pushed the dm rows out of the 16 KB scalar cache; a one-row-ahead register
+    // prefetch of H[n, m] is folded back into load-then-wait by the compiler.
+    {
+      double hv[BF_RT], hc[BF_RT / 4];
+      const int rr4 = lane / CG4, cc = lane - rr4 * CG4;         // CG4 = 16 lanes per row of hx
+#pragma unroll
+      for (int r = 0; r < BF_RT; ++r) {
+        const int64_t n = (rt + r < re) ? rt + r : re - 1;
+        hv[r] = H[n * M + mc] + g0[n];
       }
-      acc[p] += exp_tab(c0 + c1, etab);
+#pragma unroll
+      for (int k = 0; k < BF_RT / 4; ++k) {
+        const int64_t n = (rt + 4 * k + rr4 < re) ? rt + 4 * k + rr4 : re - 1;
+        const int col = (col_base + cc < M) ? col_base + cc : M - 1;
+        hc[k] = H[n * M + col];
+      }
+#pragma unroll
+      for (int r = 0; r < BF_RT; ++r) hl[r * 64 + lane] = hv[r];
+#pragma unroll
+      for (int k = 0; k < BF_RT / 4; ++k) hx[(4 * k + rr4) * CG4 + cc] = hc[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int g = 0; g < BF_G; ++g) {                            // unrolled: the accumulators of all groups stay in registers
+      const int col0 = col_base + NP * g;
+      if (col0 >= M) break;
+      int mp[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) mp[p] = (col0 + p < M) ? col0 + p : M - 1;
+      double zz[NP][QP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int q = 0; q < QP; ++q) zz[p][q] = Zc[(size_t)mc * QP + q] * Zc[(size_t)mp[p] * QP + q];
+      }
+      const int nr = (int)(re - rt);
+      for (int r = 0; r < nr; ++r) {
+        const int64_t n = rt + r;
+        const double* __restrict__ dn = dm + n * QP;            // wave-uniform: scalar loads
+        const double hcur = hl[r * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          double c0 = hcur + hx[r * CG4 + NP * g + p], c1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < QP; q += 2) {
+            c0 += zz[p][q] * dn[q];
+            c1 += zz[p][q + 1] * dn[q + 1];
+          }
+          acc[g][p] += exp_tab(c0 + c1, etab);
+        }
+      }
     }
   }
+  if (act) {
 #pragma unroll
-  for (int p = 0; p < NP; ++p)
-    if (act && NP * grp + p < M) part[((size_t)blockIdx.y * M + m) * M + NP * grp + p] = acc[p];
+    for (int g = 0; g < BF_G; ++g)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (col_base + NP * g + p < M) prow[col_base + NP * g + p] = acc[g][p];
+  }
 }
 
 // psi2[i][j] = sum over chunks of part[chunk][min(i,j)][max(i,j)]   (fixed order)
@@ -316,10 +383,16 @@ __global__ void __launch_bounds__(256) big_psi2_unpack_kernel(int M, int nchunk,
 
 static rgp_status launch_big_psi2_fwd(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, const ZTerms& zt,
                                       const RowTerms& rt, const double* dm, const double* H, double* part, double* psi2) {
-  const dim3 grid((unsigned)((p.fwd_tasks + 3) / 4), (unsigned)p.fwd_chunks);
+  const dim3 grid((unsigned)((p.fwd_tasks + 7) / 8), (unsigned)p.fwd_chunks);
+  const size_t lds = (PSI2_EXP_TAB + (size_t)8 * BF_RT * (64 + 16)) * sizeof(double);
   switch (zt.QP) {
-#define B2F(qp, np) case qp: hipLaunchKernelGGL((big_psi2_fwd_kernel<qp, np>), grid, dim3(256), 0, s, N, M, p.fwd_tasks, zt.Zc, dm, H, rt.g0, part); break;
-    B2F(8, 2) B2F(16, 2) B2F(20, 2) B2F(24, 2) B2F(32, 2) B2F(40, 2) B2F(48, 2) B2F(56, 1) B2F(64, 1)
+#define B2F(qp, np)                                                                                                        \
+  case qp: {                                                                                                               \
+    hipError_t e = hipFuncSetAttribute((const void*)big_psi2_fwd_kernel<qp, np>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 forward (blocked) LDS attr: ") + hipGetErrorString(e)); \
+    hipLaunchKernelGGL((big_psi2_fwd_kernel<qp, np>), grid, dim3(512), lds, s, N, M, p.fwd_tasks, zt.Zc, dm, H, rt.g0, part);  \
+  } break;
+    B2F(8, BF_NP) B2F(16, BF_NP) B2F(20, BF_NP) B2F(24, BF_NP) B2F(32, BF_NP) B2F(40, BF_NP) B2F(48, BF_NP) B2F(56, 1) B2F(64, 1)
 #undef B2F
     default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (blocked): unsupported padded Q");
   }

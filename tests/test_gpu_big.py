@@ -187,7 +187,7 @@ def test_big_freerun_matches_oracle(M):
     in blocks of 512 (M > 512)."""
     from test_gpu_model import compare
     o, g = _pair(n_seq=2, T=16, M=M)
-    compare(o, g, rtol=1e-8)
+    compare(o, g, rtol=1e-6)        # hundreds of inducing points in 6 to 15 input dimensions: cond(K_uu) is at the jitter's limit
     U = np.random.default_rng(8).standard_normal((12, 2))
     want, got = o.freerun(U), g.freerun(U)
     g.handle.sync()
