@@ -162,6 +162,15 @@ rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* va
 /* kern.psi1(Z, q(X)) -> N x M and kern.psi2(Z, q(X)) -> M x M (vardtc.py:60-61); either output may be NULL. */
 rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
                            const double* variance, const double* inv_l, double* psi1, double* psi2);
+/* rgp_psi_forward for callers that cannot allocate.  It has NO counterpart in the reference: it exists for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and the same results
+ * (to rounding: the psi2 partial sums are combined over fewer workgroups) as rgp_psi_forward, but it calls no hipMalloc /
+ * hipFree or any other allocating routine: its scratch (Z terms, row terms, partial sums) is a 20 MB static device array
+ * that every GPU the library runs on holds until the process ends.  Limits: N <= 4096, M <= 128, Q <= 64; larger problems
+ * are rejected with RGP_ERR_BAD_ARG.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two
+ * handles, two streams) race; consecutive calls on one stream are safe (nothing is read before this call has written it). */
+rgp_status rgp_psi_forward_static(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
+                                  const double* variance, const double* inv_l, double* psi1, double* psi2);
 /* kern.update_gradients_expectations + gradients_Z_expectations + gradients_qX_expectations (layers.py:98-132,
  * 1452-1458) for given dL_dpsi1 (N x M, may be NULL) and dL_dpsi2 (M x M, may be NULL); dL_dpsi0 enters as its sum.
  * Outputs: dvar[1], dinv_l[Q], dZ[M x Q], dmu[N x Q], dS[N x Q]. */

@@ -95,6 +95,13 @@ class Handle(object):
         self._check(self.lib.rgp_psi_forward(self.h, N, M, Q, _p(mu), _p(S), _p(Z), _p(variance), _p(inv_l), _p(p1), _p(p2)))
         return p1, p2
 
+    def psi_forward_static(self, mu, S, Z, variance, inv_l, psi1, psi2):
+        """rgp_psi_forward_static: the caller passes the output tensors too; the call allocates nothing."""
+        _chk64(mu, S, Z, variance, inv_l, psi1, psi2)
+        N, Q = mu.shape
+        M = Z.shape[0]
+        self._check(self.lib.rgp_psi_forward_static(self.h, N, M, Q, _p(mu), _p(S), _p(Z), _p(variance), _p(inv_l), _p(psi1), _p(psi2)))
+
     def psi_backward(self, mu, S, Z, variance, inv_l, dL_dpsi0_sum, dL_dpsi1, dL_dpsi2):
         _chk64(mu, S, Z, variance, inv_l, dL_dpsi1, dL_dpsi2)
         N, Q = mu.shape

@@ -95,6 +95,7 @@ struct rgp_ctx {
   hipEvent_t ev_post_tail = nullptr;     // last rgp_adam_step_post
   bool post_tail_recorded = false;
   int* status = nullptr;        // device: [0] = error code, [1] = pivot
+  char* static_scratch = nullptr;    // this device's address of the library's static scratch array (rgp_psi_forward_static)
   int num_cu = 256;
   unsigned vardtc_rr = 0;            // collapsed-bound layer steps rotate over the three streams
   int vardtc_prev_slot = -1;         // workspace slot (its ev_done) of the previous collapsed-bound layer step

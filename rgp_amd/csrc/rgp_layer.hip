@@ -10,6 +10,31 @@ void rgp_gap_dump();
 #endif
 
 // ==================================================================================================================
+// static device scratch of rgp_psi_forward_static (the entry point that allocates nothing, include/rgp_hip.h)
+// ==================================================================================================================
+// Each GPU the library runs on holds its own copy of this array until the process ends.  In host code the array's NAME is
+// only a stand-in for the symbol, not a device address: the address is looked up once per device with hipGetSymbolAddress
+// (rgp_create, that device current) and every later use -- kernel arguments, copies -- goes through that pointer.
+#define RGP_STATIC_MAX_N 4096
+#define RGP_STATIC_NBLK 128
+#define RGP_STATIC_SCRATCH_BYTES (20u << 20)
+static __device__ __align__(256) unsigned char rgp_static_scratch[RGP_STATIC_SCRATCH_BYTES];
+#define RGP_MAX_DEVICES 64
+static char* g_static_scratch_ptr[RGP_MAX_DEVICES] = {};
+
+static hipError_t static_scratch_lookup(int device, char** out) {
+  if (device < 0 || device >= RGP_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (!g_static_scratch_ptr[device]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rgp_static_scratch));       // the device is current (rgp_create)
+    if (e != hipSuccess) return e;
+    g_static_scratch_ptr[device] = static_cast<char*>(p);
+  }
+  *out = g_static_scratch_ptr[device];
+  return hipSuccess;
+}
+
+// ==================================================================================================================
 // handle
 // ==================================================================================================================
 rgp_status rgp_fail(rgp_handle h, rgp_status code, const std::string& msg) {
@@ -67,6 +92,7 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   if (hipSetDevice(device) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+  if (static_scratch_lookup(device, &h->static_scratch) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
   h->overlap = getenv("RGP_NO_OVERLAP") == nullptr;
@@ -735,6 +761,52 @@ extern "C" rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, con
     launch_unpack_tri(s, M, L.p2_tri, psi2);
   }
   return last_launch(h, "rgp_psi_forward");
+}
+
+// rgp_psi_forward without any allocation: the Z terms, the row terms and the per-workgroup partial sums of psi2 live in the
+// static device scratch.  Same kernels as rgp_psi_forward; the psi2 partials are summed over at most RGP_STATIC_NBLK
+// workgroups, so the two entry points agree to rounding (fixed order each), not bit for bit.
+extern "C" rgp_status rgp_psi_forward_static(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S,
+                                             const double* Z, const double* variance, const double* inv_l, double* psi1,
+                                             double* psi2) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  rgp_status st = check_geometry(h, N, M, Q);
+  if (st) return st;
+  if (N > RGP_STATIC_MAX_N)
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_psi_forward_static: N > 4096 exceeds the static scratch (use rgp_psi_forward)");
+  const int QP = rgp_qp(Q);
+  const int tri = M * (M + 1) / 2;
+  int64_t nb = 2 * (int64_t)h->num_cu;
+  if (nb > RGP_STATIC_NBLK) nb = RGP_STATIC_NBLK;
+  if (nb > (N + 1) / 2) nb = (N + 1) / 2;
+  const int nblk = (int)(nb < 1 ? 1 : nb);
+  ZTerms zt{};
+  RowTerms rt{};
+  WsAlloc ws(h->static_scratch);
+  const size_t nq = (size_t)N * QP;
+  zt.M = M; zt.Q = Q; zt.QP = QP;
+  zt.c = ws.take<double>(QP); zt.lam = ws.take<double>(QP); zt.Zc = ws.take<double>((size_t)M * QP);
+  zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM); zt.zd = ws.take<double>((size_t)M * M); zt.Kuu = ws.take<double>((size_t)M * M);
+  rt.N = N; rt.QP = QP;
+  rt.Xmu = ws.take<double>(nq); rt.d2 = ws.take<double>(nq); rt.e1 = ws.take<double>(nq); rt.em = ws.take<double>(nq);
+  rt.g0 = ws.take<double>(N); rt.g1 = ws.take<double>(N);
+  double* p2_part = ws.take<double>((size_t)nblk * tri);
+  double* p2_tri = ws.take<double>(tri);
+  if (ws.off > RGP_STATIC_SCRATCH_BYTES)
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_psi_forward_static: the problem does not fit the static scratch");
+  rgp_join_streams(h);
+  hipStream_t s = h->stream;
+  launch_prep_z(s, M, Q, QP, Z, variance, inv_l, RGP_JITTER, zt);
+  launch_rowprep_dense(s, N, Q, mu, S, variance, zt, rt);
+  if (psi1) launch_psi1_fwd(s, N, M, zt, rt, psi1);
+  if (psi2) {
+    Psi2Out o{};
+    o.p2_part = p2_part;
+    if ((st = launch_psi2(h, true, false, N, M, Q, zt, rt, nullptr, o, nblk))) return st;
+    launch_reduce(s, nblk, tri, tri, p2_part, p2_tri, 1.0, 0);
+    launch_unpack_tri(s, M, p2_tri, psi2);
+  }
+  return last_launch(h, "rgp_psi_forward_static");
 }
 
 extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S,
