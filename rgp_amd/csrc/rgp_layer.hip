@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "rgp_chain.h"
+#include "rgp_gemm.h"
 #include "rgp_psi.h"
 #ifdef RGP_GAPPROF
 void rgp_gap_dump();
@@ -379,6 +380,13 @@ __global__ void __launch_bounds__(256) vardtc_rows_kernel(int64_t N, int M, int 
       }
     }
   }
+}
+
+// dYm -= Ym / noise    (the -beta Ym term of dL/dYmean, svi_vardtc.py:192)
+__global__ void __launch_bounds__(256) dym_noise_kernel(int64_t n, const double* __restrict__ Ym, const double* __restrict__ noise,
+                                                         double* __restrict__ dYm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dYm[i] -= Ym[i] / noise[0];
 }
 
 __global__ void symmetrise_kernel(int M, const double* __restrict__ A, double* __restrict__ out) {
@@ -1275,6 +1283,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // psi1 side
   bool psi1_fast = false;
+  int psi1y_splits = L.nblk1;                                  // partial slabs of psi1Y to reduce
   if (psi1_svi_supported(D)) {
     if (h->overlap) RGP_HIP_CHECK(h, wait_if_pending(s, h->ev_pre_a[slot]));  // Cpsi1 comes from the chain's first kernel
     GAP_MARK(1, false);
@@ -1284,20 +1293,34 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     // on the main stream reads them
     psi1_fast = true;
   } else {
-    launch_psi1_fwd(s, N, M, L.zt, L.rt, L.psi1);
-    if (h->overlap) RGP_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_pre[slot], 0));
-    {
-      const size_t lds = (size_t)M * (D + 1) * sizeof(double);
-      int64_t b = (N + 3) / 4; if (b > 2048) b = 2048;
-      hipLaunchKernelGGL(svi_rows_kernel, dim3((unsigned)b), dim3(256), lds, s, N, M, D, L.Ym, c.Cpsi1, L.psi1, in->noise,
-                         L.Lp /* dLdpsi1, overwritten in place by Lp below */, in->y_uncertain ? L.dYm : nullptr);
+    // wide outputs (D > 16): the contractions over d run on the MFMA GEMM, the three passes keep their D-free parts
+    if (h->overlap) RGP_HIP_CHECK(h, wait_if_pending(s, h->ev_pre_a[slot]));  // Cpsi1 comes from the chain's first kernel
+    GAP_MARK(1, false);
+    {                                                          // T = Ym Cpsi1^T   (dL/dpsi1 up to beta, svi_vardtc.py:164-167)
+      GemmArgs g;
+      g.m = (int)N; g.n = M; g.k = D; g.A = L.Ym; g.lda = D; g.B = c.Cpsi1; g.ldb = D; g.tb = 1; g.C = L.Lp; g.ldc = M;
+      launch_gemm(s, g);
     }
-    launch_colmm(s, N, D, M, L.Ym, L.psi1, nullptr, L.psi1Y_part, L.psi1Y, L.nblk1);
-    launch_psi1_bwd(s, N, M, Q, L.zt, L.rt, L.Lp, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.nblk1);
-    launch_reduce(s, L.nblk1, QP, QP, L.dlam1_part, L.dlam1, 1.0, 0);
-    launch_reduce(s, L.nblk1, 1, 1, L.lsum1_part, L.lsum1, 1.0, 0);
-    launch_psi1_dz(s, N, M, L.zt, L.rt, L.Lp, L.dz1_part, L.nblk1);
-    launch_reduce(s, L.nblk1, (int64_t)M * QP, (int64_t)M * QP, L.dz1_part, L.dz1, 1.0, 0);
+    launch_psi1_svi_wide(s, N, M, Q, L.zt, L.rt, in->noise, L.psi1, L.Lp, L.gmu, L.gS, L.dlam1_part, L.lsum1_part, L.dz1_part,
+                         L.nblk1);
+    {                                                          // psi1Y = Ym^T psi1 (D x M): split over the rows, partials reduced below
+      int64_t sk = (N + 1023) / 1024;
+      if (sk > L.nblk1) sk = L.nblk1;
+      psi1y_splits = (int)(sk < 1 ? 1 : sk);
+      GemmArgs g;
+      g.m = D; g.n = M; g.k = (int)N; g.A = L.Ym; g.lda = D; g.ta = 1; g.B = L.psi1; g.ldb = M; g.C = L.psi1Y_part; g.ldc = M;
+      g.splits = psi1y_splits; g.split_stride = (int64_t)D * M;
+      if (psi1y_splits == 1) g.splits = 2;                     // at least two splits: the output keeps the partial-slab layout
+      psi1y_splits = g.splits;
+      launch_gemm(s, g);
+    }
+    if (in->y_uncertain) {                                     // dL/dYmean = psi1 Cpsi1 - beta Ym   (svi_vardtc.py:192)
+      GemmArgs g;
+      g.m = (int)N; g.n = D; g.k = M; g.A = L.psi1; g.lda = M; g.B = c.Cpsi1; g.ldb = D; g.C = L.dYm; g.ldc = D;
+      launch_gemm(s, g);
+      hipLaunchKernelGGL(dym_noise_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, s, N * D, L.Ym, in->noise, L.dYm);
+    }
+    psi1_fast = true;
   }
 
   Psi2Plan pl2;
@@ -1353,7 +1376,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
     ReduceSeg segs[8];
     int ns = 0;
     if (psi1_fast) {
-      segs[ns++] = {L.psi1Y_part, L.psi1Y, L.nblk1, (int64_t)D * M, (int64_t)D * M};
+      segs[ns++] = {L.psi1Y_part, L.psi1Y, psi1y_splits, (int64_t)D * M, (int64_t)D * M};
       segs[ns++] = {L.dlam1_part, L.dlam1, rb, QP, QP};
       segs[ns++] = {L.lsum1_part, L.lsum1, rb, 1, 1};
       segs[ns++] = {L.dz1_part, L.dz1, L.nblk1, (int64_t)M * QP, (int64_t)M * QP};

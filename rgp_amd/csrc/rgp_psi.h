@@ -93,6 +93,11 @@ int psi1_svi_rows_blocks(int64_t N);
 void launch_psi1_svi(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms& zt, const RowTerms& rt, const double* Ym,
                      const double* Cpsi1, const double* noise, double* P, double* Lp, double* psi1Y_part, double* gmu,
                      double* gS, double* dYm, double* dlam_part, double* lsum_part, double* dz_part, int nblk);
+// the same three passes for wide outputs (any D): Lp holds T = Ym Cpsi1^T on entry and Lp = psi1 o T on exit; P = psi1;
+// psi1Y = Ym^T P and dL/dY = P Cpsi1 - beta Ym are products the caller runs on the GEMM kernel
+void launch_psi1_svi_wide(hipStream_t s, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt, const double* noise,
+                          double* P, double* Lp, double* gmu, double* gS, double* dlam_part, double* lsum_part, double* dz_part,
+                          int nblk);
 // fused psi2 pass: forward sum (tri-packed partials) and/or backward for given symmetric dLs (M x M)
 struct Psi2Out {
   double* p2_part;     // [nblk x tri]           (forward)

@@ -636,6 +636,64 @@ psi1_svi_fwd2_kernel(const int64_t N, const int M, const int D, const double* __
   }
 }
 
+// pass F for wide outputs (D > 16): the D-sized register arrays of the kernels above do not scale, so the two contractions
+// over d run as GEMMs (T = Ym Cpsi1^T before this kernel, psi1Y = Ym^T P after it) and the kernel only evaluates
+// P = psi1 and Lp = P o T in place (Lp holds T on entry).  Same staging of the row operands as psi1_svi_fwd_kernel.
+template <int QP>
+__global__ void __launch_bounds__(256, 2)
+psi1_svi_fwdT_kernel(const int64_t N, const int M, const double* __restrict__ Zc, const double* __restrict__ e1,
+                     const double* __restrict__ em, const double* __restrict__ g1, double* __restrict__ P, double* Lp) {
+  __shared__ __attribute__((aligned(16))) double buf[2 * P1_TILE * QP];
+  __shared__ double gs[P1_TILE];
+  double2* ee = reinterpret_cast<double2*>(buf);
+  const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1), team = t >> 7;
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  double z[QP];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) z[q] = Zc[(size_t)tm * QP + q];
+  const int64_t per = ((N + gridDim.x - 1) / gridDim.x + P1_TILE - 1) / P1_TILE * P1_TILE;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  for (int64_t rb = r0; rb < r1; rb += P1_TILE) {
+    const int nr = (int)((r1 - rb) < P1_TILE ? (r1 - rb) : P1_TILE);
+    __syncthreads();
+    {
+      const int64_t lim = (int64_t)nr * QP - 1;
+      constexpr int NE = (P1_TILE * QP + 255) / 256;
+      double2 v[NE];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int64_t i = t + 256 * k, ic = i < lim ? i : lim;
+        v[k] = make_double2(e1[rb * QP + ic], em[rb * QP + ic]);
+      }
+      const double gv = g1[rb + (t < nr ? t : nr - 1)];
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        if (t + 256 * k < P1_TILE * QP) ee[t + 256 * k] = v[k];
+      if (t < P1_TILE) gs[t] = gv;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = team; r < nr; r += 2) {
+      const double2* er = ee + r * QP;
+      const double tv = act ? Lp[(rb + r) * M + tr] : 0.0;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; q += 2) {
+        const double2 x0 = er[q], x1 = er[q + 1];
+        a0 += z[q] * (x0.x * z[q] - 2.0 * x0.y);
+        a1 += z[q + 1] * (x1.x * z[q + 1] - 2.0 * x1.y);
+      }
+      const double p = exp(gs[r] - 0.5 * (a0 + a1));
+      if (act) {
+        Lp[(rb + r) * M + tr] = tv * p;
+        if (P) P[(rb + r) * M + tr] = p;
+      }
+    }
+  }
+}
+
 // pass Z.  Lane = two inducing rows (m, m + 64), wave = one quarter of the q columns; all four waves walk all rows of the
 // tile.  One broadcast ds_read_b128 of (e, e*mu)[row, q] then feeds four multiply-adds instead of two, and a (m, q) slot has
 // exactly one owner, so nothing is combined at the end.  The Lp tile is staged in LDS (coalesced 128-column rows).
@@ -908,6 +966,33 @@ void launch_psi1_svi(hipStream_t s, int64_t N, int M, int Q, int D, const ZTerms
     default: break;
   }
 #undef P1S
+}
+
+// Wide outputs (D > 16): passes F (with T = Ym Cpsi1^T already in Lp), R (row gradients; dL/dY is a GEMM of the caller) and Z.
+template <int QP>
+static void psi1_svi_wide_dispatch(hipStream_t s, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt,
+                                   const double* noise, double* P, double* Lp, double* gmu, double* gS, double* dlam_part,
+                                   double* lsum_part, double* dz_part, int nblk) {
+  hipLaunchKernelGGL((psi1_svi_fwdT_kernel<QP>), dim3(nblk), dim3(256), 0, s, N, M, zt.Zc, rt.e1, rt.em, rt.g1, P, Lp);
+  const int rb = psi1_svi_rows_blocks(N);
+  if ((N + 63) / 64 < 640)
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false, 4>), dim3(rb), dim3(256), 0, s, N, M, Q, 1, zt.Zc, zt.lam, rt.Xmu,
+                       rt.e1, Lp, Lp, Lp, Lp, noise, gmu, gS, nullptr, dlam_part, lsum_part);
+  else
+    hipLaunchKernelGGL((psi1_svi_rows_kernel<QP, 1, false, 2>), dim3(rb), dim3(128), 0, s, N, M, Q, 1, zt.Zc, zt.lam, rt.Xmu,
+                       rt.e1, Lp, Lp, Lp, Lp, noise, gmu, gS, nullptr, dlam_part, lsum_part);
+  hipLaunchKernelGGL((psi1_svi_dz_kernel<QP>), dim3(nblk), dim3(256), 0, s, N, M, zt.Zc, rt.e1, rt.em, Lp, dz_part);
+}
+
+void launch_psi1_svi_wide(hipStream_t s, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt, const double* noise,
+                          double* P, double* Lp, double* gmu, double* gS, double* dlam_part, double* lsum_part, double* dz_part,
+                          int nblk) {
+  switch (zt.QP) {
+#define P1W(qp) case qp: psi1_svi_wide_dispatch<qp>(s, N, M, Q, zt, rt, noise, P, Lp, gmu, gS, dlam_part, lsum_part, dz_part, nblk); break;
+    P1W(8) P1W(16) P1W(20) P1W(24) P1W(32) P1W(40) P1W(48) P1W(56) P1W(64)
+#undef P1W
+    default: break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

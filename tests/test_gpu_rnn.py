@@ -159,3 +159,62 @@ def test_chain_carry_over_equals_plain_steps():
         assert abs(ea - eb) <= 1e-10 * abs(eb), (k, ea, eb)
     a.handle.sync(); b.handle.sync()
     assert float((a.param_array[:a.n_global] - b.param_array[:b.n_global]).abs().max()) <= 1e-10 * float(b.param_array[:b.n_global].abs().max())
+
+
+def test_config3_geometry_matches_oracle():
+    """BASELINE config 3 at its geometry (walk_run mocap: D_y = 59, D_u = 1, wins = [0, 20, 20], U_win = 20, M = 100, GRU
+    encoder; examples/walk_run_2_alex.py:364-393): ELBO and every gradient group of the three GP layers against the oracle on
+    the encoder-produced q(X) (ELBO 1e-9, gradients 1e-8), plus central differences on encoder weights."""
+    import torch
+    from oracle import model as om
+    from rgp_amd.model import DeepAutoreg_rnn
+    n_seq, T, wins, nDims, M, Uw = 4, 100, [0, 20, 20], [59, 1, 1], 100, 20
+    U, Y = make_data(n_seq, T, u_dim=1, y_dim=59, seed=6)
+    m = DeepAutoreg_rnn(wins, Y, U=U, U_win=Uw, nDims=nDims, num_inducing=M, rnn_type='gru', rnn_hidden_dims=[40],
+                        inference_method='svi', mb_inf_tot_data_size=n_seq, seed=1)
+    rng = np.random.default_rng(2)
+    for L in m.layers:
+        m.set_param(L, 'inv_l', (0.3 + rng.random(L.Q)) * 4.0 / L.Q)
+        m.set_param(L, 'noise', 0.2 + 0.1 * rng.random())
+        m.set_param(L, 'qU_W', rng.standard_normal((L.M, L.M)) * 0.05)
+        m.set_param(L, 'qU_a', 0.3)
+    e = float(m.evaluate().item())
+    m.handle.sync()
+    o = om.DeepAutoreg(wins, Y, U=U, U_win=Uw, nDims=nDims, num_inducing=M, init='Y', inference_method='svi',
+                       rng=np.random.default_rng(0), fast_psi=True, chunk=64, latent_full=True)
+    for L in m.layers:
+        p = o.P[L.index]
+        for nm in ('Z', 'inv_l', 'qU_m', 'qU_W'):
+            getattr(p, nm)[...] = m.view(L, nm).cpu().numpy()
+        p.variance = float(m.view(L, 'variance').item()); p.noise = float(m.view(L, 'noise').item())
+        p.qU_a = float(m.view(L, 'qU_a').item())
+    for i in (1, 2):
+        for s in range(n_seq):
+            o.Xmean[i][s][...] = m.latent(i, s).cpu().numpy()
+            o.Xvar[i][s][...] = m.latent(i, s, var=True).cpu().numpy()
+    eo, Go = o.elbo_and_grads()
+    assert abs(e - eo) <= 1e-9 * abs(eo), (e, eo)
+    Gg = m.grads_as_oracle_dict()
+    for k, v in Go.items():
+        a, b = np.asarray(Gg[k], dtype=float), np.asarray(v, dtype=float)
+        scale = max(np.abs(b).max(), 1e-12)
+        assert np.abs(a.reshape(b.shape) - b).max() <= 1e-8 * scale, (k, np.abs(a.reshape(b.shape) - b).max(), scale)
+    # encoder weights: analytic gradient (device GP gradients pushed through the encoder) vs central differences of the ELBO
+    g = m.encoder_grad_vector().cpu().numpy().copy()
+    off = 0
+    eps = 1e-6
+    for p_ in m.encoder.parameters():
+        n = p_.numel()
+        j = int(rng.integers(n))
+        old = float(p_.view(-1)[j].item())
+        with torch.no_grad():
+            p_.view(-1)[j] = old + eps
+        ep = float(m.evaluate().item())
+        with torch.no_grad():
+            p_.view(-1)[j] = old - eps
+        em = float(m.evaluate().item())
+        with torch.no_grad():
+            p_.view(-1)[j] = old
+        num = (ep - em) / (2 * eps)
+        assert abs(num - g[off + j]) <= 1e-4 * max(1.0, abs(num)), (off + j, num, g[off + j])
+        off += n
