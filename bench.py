@@ -162,7 +162,7 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, DESIGN.md section 5 ----
+        # ---- roofline of the dominant kernel ----
         # algorithmic flops per (row, m, m') of the factorised form: Gram 2Q + y-update 2Q; the N*M*M exp evaluations are
         # listed separately (no fp64 transcendental unit: 14 VALU instructions each).
         flops = 4.0 * psi2_nmmq                      # 4 Q flop per (n, m, m')
@@ -200,7 +200,7 @@ def main():
                          'avg_launch_ms': psi2_ms / max(psi2_n, 1), 'launches': psi2_n,
                          'algorithmic_flop_per_launch': flops / max(psi2_n, 1),
                          'note': 'flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
-                                 'evaluations are extra VALU work not counted; SURVEY 8d counts 10*N*M*M*Q for the GPy form'},
+                                 'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q'},
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, Us, Ys, m, mb, n_total, T)

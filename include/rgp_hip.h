@@ -3,8 +3,8 @@
  * Cholesky/Woodbury algebra of the collapsed / SVI bound, all gradients, and the window scatter-add).
  *
  * The reference (zhenwendai/RGP) is pure Python with NO FFI; its seams are duck-typed Python protocols
- * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces.  A maintainer of the
- * reference would bind these with ctypes from autoreg/layers.py (stub in INTEGRATION.md).
+ * (GPy's kernel / inference-method / posterior objects).  Each entry point below names the reference interface it
+ * replaces.  A maintainer of the reference would bind these with ctypes from autoreg/layers.py, as rgp_amd/_lib.py does.
  *
  * Conventions
  *  - plain C linkage, POD structs, no exceptions; every call returns rgp_status (0 = ok);

@@ -52,7 +52,7 @@ class Stats(object):
 def vardtc(Kuu, st, noise_var):
     """Collapsed (Titsias) bound with uncertain inputs and optionally uncertain outputs.
 
-    Returns (logL, grad dict, woodbury_inv, woodbury_vector).  SURVEY.md Appendix A.2."""
+    Returns (logL, grad dict, woodbury_inv, woodbury_vector)."""
     N, D = st.Ymean.shape
     M = Kuu.shape[0]
     beta = 1.0 / max(float(noise_var), 1e-6)                      # vardtc.py:102
@@ -104,8 +104,7 @@ def svi(Kuu, st, noise_var, qU_mean, qU_var):
     """Uncollapsed (Hensman) bound with explicit q(U)=N(qU_mean, qU_var) shared by the D outputs.
 
     Returns (logL, grad dict, woodbury_inv, woodbury_vector, mid) where ``mid`` carries the
-    factors KL needs (the reference stashes them in ``self.mid``, svi_vardtc.py:100-104).
-    SURVEY.md Appendix A.3."""
+    factors KL needs (the reference stashes them in ``self.mid``, svi_vardtc.py:100-104)."""
     N, D = st.Ymean.shape
     M = Kuu.shape[0]
     beta = 1.0 / float(noise_var)                                  # svi_vardtc.py:80

@@ -15,7 +15,7 @@ GPy.core.SparseGP, paramz, GPy.kern, GPy.likelihoods), so this file RESTATES the
   * q(U) initialisation                              layers.py:51-58, util.py:32-38
   * minibatch qU_ratio                               layers.py:231-232,328-329
   * free-run with moment matching                    layers.py:1537-1571, model.py:725-740
-    (+ GPy SparseGP._raw_predict, restated from upstream; "parity unpinned")
+    (+ GPy SparseGP._raw_predict, restated from upstream and pinned by quadrature in tests/test_oracle_layers_golden.py)
 
 What pins it: the inference pieces it composes are pinned to the reference by tests/test_oracle_golden.py;
 the window indexing by hand-computed cases and the exact-adjoint/finite-difference check in

@@ -8,8 +8,7 @@ gradients_qX_expectations / update_gradients_full / gradients_X``), called from
 
 GPy is a third-party dependency that is NOT vendored under /root/reference and is not pinned
 there (no setup.py / requirements); the closed forms restated here are GPy's published
-``GPy/kern/src/psi_comp/rbf_psi_comp.py`` formulas for ``RBF(ARD=True, inv_l=True)``
-(SURVEY.md Appendix A.1).  Absolute psi values are therefore "parity unpinned" by the reference
+``GPy/kern/src/psi_comp/rbf_psi_comp.py`` formulas for ``RBF(ARD=True, inv_l=True)``.  Absolute psi values are therefore "parity unpinned" by the reference
 itself; this module pins them against the *definition* (Gaussian expectation of the kernel) by
 Gauss-Hermite quadrature in tests/test_oracle_psi.py, and every gradient against central finite
 differences.
@@ -139,7 +138,7 @@ def psi_grads_direct(variance, inv_l, Z, mu, S, dL_dpsi0, dL_dpsi1, dL_dpsi2):
 
 # ----------------------------------------------------------------------------------------------
 # psi statistics, chunked GEMM form (CPU baseline; GPy's own structure: the data-dependent part of
-# the psi2 exponent is [N x 2Q] . [2Q x M^2], SURVEY.md Appendix A.1)
+# the psi2 exponent is [N x 2Q] . [2Q x M^2])
 # ----------------------------------------------------------------------------------------------
 
 class PsiStatsFast(object):

@@ -2,7 +2,7 @@
 //
 // What the reference computes through GPy (kern.K / psi1 / psi2 and their gradients; call sites
 // autoreg/inference/vardtc.py:59-61,110, svi_vardtc.py:48-50,88, autoreg/layers.py:98-134,1452-1458) is done here
-// in a factorised form (DESIGN.md section 3):
+// in a factorised form:
 //
 //   psi2n[n,m,m'] = exp( zd[m,m'] + g0[n] + h[n,m] + h[n,m'] - 1/2 sum_q d2[n,q] z[m,q] z[m',q] )
 //   h[n,m]        = sum_q d2[n,q] z[m,q] (mu[n,q] - z[m,q]/4),   z = Z - c,  mu = window mean - c

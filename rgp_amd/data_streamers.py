@@ -1,9 +1,9 @@
-"""Minibatch iterators over lists of sequences, with the semantics of /root/reference/autoreg/data_streamers.py
-(SURVEY.md section 8f item 4).  Because the model keeps every sequence resident on the device, a streamer's job here is
+"""Minibatch iterators over lists of sequences, with the semantics of /root/reference/autoreg/data_streamers.py.
+Because the model keeps every sequence resident on the device, a streamer's job here is
 to say WHICH sequences form the next minibatch; the data lists are still returned so the call signature
 ``next_minibatch() -> (minibatch_index, sample_indexes, Y_out, X_out)`` matches the reference (data_streamers.py:61,143,237).
 
-Reference behaviour kept on purpose (SURVEY.md Appendix D): ``TrivialDataStreamer`` and
+Reference behaviour kept on purpose: ``TrivialDataStreamer`` and
 ``RandomPermutationDataStreamer`` use minibatch_size == total_size, i.e. they always return the whole set (the latter in
 a fresh random order); only ``StdMemoryDataStreamer`` walks through the data in contiguous chunks and wraps around."""
 import random

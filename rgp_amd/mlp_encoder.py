@@ -1,4 +1,4 @@
-"""MLP back-constraint of the hidden layers (SURVEY.md section 8 row a18): the recognition recursion of autoreg.layers.Layer
+"""MLP back-constraint of the hidden layers: the recognition recursion of autoreg.layers.Layer
 with ``back_cstr=True`` (/root/reference/autoreg/layers.py:398-441 _init_encoder, :623-666 _encoder_freerun, :668-756
 _encoder_update_gradient) and its network (/root/reference/autoreg/mlp.py:13-175, Theano there).
 
@@ -95,28 +95,119 @@ def _inv_softplus(x):
 class MlpBackConstraint(nn.Module):
     """Recursion networks and free latent parameters of all hidden layers (equal-length sequences, batched over them).
 
-    layers: list of dicts, top hidden layer FIRST, with keys X_win, X_dim, U_win, U_dim, N (predicted rows), up_len."""
+    layers: list of dicts, top hidden layer FIRST, with keys X_win, X_dim, U_win, U_dim, N (predicted rows), up_len.
 
-    def __init__(self, layers, n_seq, X_variance=0.01, MLP_dims=None):
+    Parameterisations of the per-sequence quantities (layers.py:408-439):
+      minibatch_inference=False: every sequence owns its first X_win rows (mean and variance) and one variance per
+        predicted row (layers.py:436-439);
+      minibatch_inference=True: ``init_xs_means`` (the reference's mb_inf_init_xs_means) selects the first X_win rows --
+        'one': a single (mean, variance) block shared by all sequences, gradients summed over the minibatch
+        (layers.py:412,725-732); 'all': one block per sequence of the whole data set (layers.py:415-416; all n_seq blocks
+        live on the device and a minibatch indexes them, which is what the reference's save / load on every minibatch
+        switch amounts to, layers.py:342-362); 'mlp': the means are the output of one more network per layer applied to the
+        first rows of the layer below -- the observations for the lowest hidden layer -- bottom-up
+        (model.py:113-124,165-171, layers.py:443-472; dims [Q, Q^2, X_win X_dim]); the reference leaves this mode
+        unfinished (layers.py:739 raises, :771 and model.py:115 stop in the debugger), so its gradient here is simply the
+        chain rule through those networks, and the first rows' variances stay at X_variance as there (layers.py:473).
+        ``init_xs_vars`` (mb_inf_init_xs_vars) selects the variances of the predicted rows -- 'one': a single X_dim vector
+        for all sequences and rows (layers.py:429,744-746); 'all': one X_dim vector per sequence, the same for every row
+        (layers.py:432-433,750)."""
+
+    def __init__(self, layers, n_seq, X_variance=0.01, MLP_dims=None, minibatch_inference=False, init_xs_means='all',
+                 init_xs_vars='all', low_init=None, init_MLP_dims=None):
         nn.Module.__init__(self)
+        assert init_xs_means in ('one', 'all', 'mlp') and init_xs_vars in ('one', 'all')
         self.specs = layers
+        self.n_seq = n_seq
+        self.minibatch_inference = bool(minibatch_inference)
+        self.means_mode = init_xs_means if minibatch_inference else 'all'
+        self.vars_mode = (init_xs_vars if minibatch_inference else 'rows')
         self.nets = nn.ModuleList()
+        self.init_nets = nn.ModuleList()
         self.init_mean = nn.ParameterList()
         self.init_var_raw = nn.ParameterList()
         self.var_raw = nn.ParameterList()
+        self.X_variance = float(X_variance)
         for sp in layers:
             Q = sp['X_win'] * sp['X_dim'] + sp['U_win'] * sp['U_dim']
             assert sp['X_win'] > 0, 'Neural Network constraints only applies autoregressive structure!'      # layers.py:403
             dims = [Q, 2 * Q, Q + sp['X_dim'] // 2, sp['X_dim']] if MLP_dims is None else [Q] + list(MLP_dims) + [sp['X_dim']]
             self.nets.append(_mlp(dims))
-            self.init_mean.append(nn.Parameter(torch.randn(n_seq, sp['X_win'], sp['X_dim']) * 1e-2))            # layers.py:437
-            v = torch.full((n_seq, sp['X_win'] + sp['N'], sp['X_dim']), float(X_variance))
-            self.init_var_raw.append(nn.Parameter(_inv_softplus(v[:, :sp['X_win']])))
-            self.var_raw.append(nn.Parameter(_inv_softplus(v[:, sp['X_win']:])))
+            n_init = {'one': 1, 'all': n_seq, 'mlp': 0}[self.means_mode]
+            if n_init:
+                if self.minibatch_inference:
+                    im = torch.zeros(n_init, sp['X_win'], sp['X_dim'])                                          # layers.py:412-416
+                else:
+                    im = torch.randn(n_init, sp['X_win'], sp['X_dim']) * 1e-2                                   # layers.py:437
+                self.init_mean.append(nn.Parameter(im))
+                self.init_var_raw.append(nn.Parameter(_inv_softplus(torch.full((n_init, sp['X_win'], sp['X_dim']), float(X_variance)))))
+            shape = {'rows': (n_seq, sp['N'], sp['X_dim']), 'all': (n_seq, 1, sp['X_dim']), 'one': (1, 1, sp['X_dim'])}[self.vars_mode]
+            self.var_raw.append(nn.Parameter(_inv_softplus(torch.full(shape, float(X_variance)))))
+        if self.means_mode == 'mlp':
+            assert low_init is not None, "init_xs_means='mlp' needs the first rows of the observations (low_init)"
+            self.register_buffer('low_init', torch.as_tensor(low_init, dtype=torch.float64).reshape(n_seq, -1))
+            q_low = self.low_init.shape[1]
+            nets = []
+            for sp in reversed(layers):                                          # lowest hidden layer first (model.py:121-124)
+                d_out = sp['X_win'] * sp['X_dim']
+                nets.append(_mlp([q_low] + ([q_low * q_low] if init_MLP_dims is None else list(init_MLP_dims)) + [d_out]))
+                q_low = d_out
+            self.init_nets.extend(reversed(nets))                                # stored like specs: top hidden layer first
         self.double()
         self.softplus = nn.Softplus()
 
     handle = None           # rgp_amd.capi.Handle: set by the model; without it only forward_loop is available
+
+    # ------------------------------------------------------------------------------------------------------------
+    def per_sequence_parameters(self):
+        """Parameters whose leading dimension runs over the sequences of the data set (a minibatch touches some rows only)."""
+        out = []
+        if self.means_mode == 'all':
+            out += list(self.init_mean) + list(self.init_var_raw)
+        if self.vars_mode in ('rows', 'all'):
+            out += list(self.var_raw)
+        return out
+
+    def shared_parameters(self):
+        """Parameters every sequence depends on: replicated across data-parallel ranks, gradients summed."""
+        per_seq = set(id(p) for p in self.per_sequence_parameters())
+        return [p for p in self.parameters() if id(p) not in per_seq]
+
+    def _batch(self, idx):
+        if isinstance(idx, slice):
+            return len(range(*idx.indices(self.n_seq)))
+        return int(idx.numel())
+
+    def _initial_rows(self, idx):
+        """(means, variances) of the first X_win rows of every hidden layer for the sequences ``idx``, lists like specs."""
+        B = self._batch(idx)
+        ms, vs = [], []
+        if self.means_mode == 'mlp':
+            low = self.low_init[idx]
+            ms = [None] * len(self.specs)
+            for k in range(len(self.specs) - 1, -1, -1):                        # bottom-up (model.py:167-171)
+                sp = self.specs[k]
+                out = self.init_nets[k](low)
+                ms[k] = out.view(B, sp['X_win'], sp['X_dim'])
+                low = out
+            vs = [torch.full((B, sp['X_win'], sp['X_dim']), self.X_variance, dtype=torch.float64, device=low.device)
+                  for sp in self.specs]
+            return ms, vs
+        for k, sp in enumerate(self.specs):
+            if self.means_mode == 'one':
+                ms.append(self.init_mean[k].expand(B, -1, -1))
+                vs.append(self.softplus(self.init_var_raw[k]).expand(B, -1, -1))
+            else:
+                ms.append(self.init_mean[k][idx])
+                vs.append(self.softplus(self.init_var_raw[k][idx]))
+        return ms, vs
+
+    def _row_variances(self, k, idx):
+        sp = self.specs[k]
+        if self.vars_mode == 'rows':
+            return self.softplus(self.var_raw[k][idx])
+        v = self.softplus(self.var_raw[k] if self.vars_mode == 'one' else self.var_raw[k][idx])
+        return v.expand(self._batch(idx), sp['N'], sp['X_dim'])                 # layers.py:657: one vector for all rows
 
     def _scan_ok(self, k):
         lins = [mod for mod in self.nets[k] if hasattr(mod, 'weight')]
@@ -133,25 +224,26 @@ class MlpBackConstraint(nn.Module):
             raise RuntimeError('MlpBackConstraint.forward needs the librgp_hip handle (set .handle); forward_loop is the torch graph')
         means, variances = [], []
         up = None if controls is None else controls[idx]
+        init_m, init_v = self._initial_rows(idx)
         for k, sp in enumerate(self.specs):
             ok, lins, dims = self._scan_ok(k)
             if not ok:
-                m = self._loop_layer(k, up, idx)
+                m = self._loop_layer(k, up, init_m[k])
             else:
                 wb = []
                 for l in lins:
                     wb += [l.weight, l.bias]
-                m = _MlpScanFn.apply(self.handle, sp, dims, self.init_mean[k][idx], up if sp['U_win'] > 0 else None, *wb)
-            v = torch.cat((self.softplus(self.init_var_raw[k][idx]), self.softplus(self.var_raw[k][idx])), dim=1)
+                m = _MlpScanFn.apply(self.handle, sp, dims, init_m[k], up if sp['U_win'] > 0 else None, *wb)
+            v = torch.cat((init_v[k], self._row_variances(k, idx)), dim=1)
             means.append(m)
             variances.append(v)
             up = m
         return means, variances
 
-    def _loop_layer(self, k, up, idx):
+    def _loop_layer(self, k, up, init_mean):
         sp = self.specs[k]
         Xw, N, Uw = sp['X_win'], sp['N'], sp['U_win']
-        rows = list(self.init_mean[k][idx].unbind(dim=1))                   # X_win tensors (batch, X_dim)
+        rows = list(init_mean.unbind(dim=1))                                # X_win tensors (batch, X_dim)
         net = self.nets[k]
         if Uw > 0:
             u_off = up.shape[1] - N - Uw + 1
@@ -166,10 +258,46 @@ class MlpBackConstraint(nn.Module):
         """The same recursion as a PyTorch graph, one network call per time step (reference of the scan)."""
         means, variances = [], []
         up = None if controls is None else controls[idx]
+        init_m, init_v = self._initial_rows(idx)
         for k, sp in enumerate(self.specs):
-            m = self._loop_layer(k, up, idx)
-            v = torch.cat((self.softplus(self.init_var_raw[k][idx]), self.softplus(self.var_raw[k][idx])), dim=1)
+            m = self._loop_layer(k, up, init_m[k])
+            v = torch.cat((init_v[k], self._row_variances(k, idx)), dim=1)
             means.append(m)
             variances.append(v)
             up = m                                                               # the layer below takes these means as its input
         return means, variances
+
+
+class RowAdam(object):
+    """Adam (ascent) for the recursion parameters.  A per-sequence parameter keeps one step count per sequence and only the
+    rows of the sequences in the minibatch move, so the moments of an untouched sequence neither decay nor push it."""
+
+    def __init__(self, encoder, b1=0.9, b2=0.999, eps=1e-8):
+        self.enc, self.b1, self.b2, self.eps = encoder, b1, b2, eps
+        per_seq = set(id(p) for p in encoder.per_sequence_parameters())
+        self.state = []
+        for p in encoder.parameters():
+            rows = id(p) in per_seq
+            t = torch.zeros(p.shape[0], dtype=torch.float64, device=p.device) if rows else [0]
+            self.state.append((p, rows, torch.zeros_like(p), torch.zeros_like(p), t))
+
+    @torch.no_grad()
+    def step(self, idx, lr):
+        for p, rows, m, v, t in self.state:
+            if p.grad is None:
+                continue
+            if rows:
+                g = p.grad[idx]
+                t[idx] += 1
+                tt = t[idx].view(-1, *([1] * (p.dim() - 1)))
+                mi = m[idx].mul_(self.b1).add_(g, alpha=1 - self.b1)
+                vi = v[idx].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                m[idx], v[idx] = mi, vi
+                upd = (mi / (1 - self.b1 ** tt)) / ((vi / (1 - self.b2 ** tt)).sqrt() + self.eps)
+                p[idx] = p[idx] + lr * upd
+            else:
+                t[0] += 1
+                m.mul_(self.b1).add_(p.grad, alpha=1 - self.b1)
+                v.mul_(self.b2).addcmul_(p.grad, p.grad, value=1 - self.b2)
+                tt = t[0]
+                p.add_(lr * (m / (1 - self.b1 ** tt)) / ((v / (1 - self.b2 ** tt)).sqrt() + self.eps))

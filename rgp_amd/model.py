@@ -10,7 +10,7 @@ What lives where
 Parameter layout -- ONE flat fp64 device tensor ``param_array`` (constrained values, like paramz' param_array) and a
 mirror ``grad_array``:
     [ global parameters of every layer, top layer first | ELBO slot | latent means | latent variances ]
-  * the global segment (+ELBO slot) is the single all-reduce bucket of data-parallel SVI (SURVEY.md section 8e);
+  * the global segment (+ELBO slot) is the single all-reduce bucket of data-parallel SVI;
   * latent means / variances are grouped per SEQUENCE (for s: for hidden layer i top..1: T_{s,i} x H_i block), so the
     local parameters of a contiguous minibatch are one contiguous range.
 """
@@ -765,7 +765,73 @@ class DeepAutoreg(object):
 DeepAutoreg_new = DeepAutoreg
 
 
-class DeepAutoreg_rnn(DeepAutoreg):
+class _EncoderParamsMixin(object):
+    """Flat parameter access, checkpoints and L-BFGS for the models whose q(X) comes from a recognition network: the free
+    parameters are the GP globals and the network's own parameters (paramz links both under the model, model.py:400-440
+    and layers.py:272-296), not the latent rows, so the flat vector is [GP globals (optimiser space) | encoder parameters]."""
+
+    def _enc_flat(self, grad=False):
+        ps = list(self.encoder.parameters())
+        if grad:
+            return torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in ps])
+        return torch.cat([q.detach().reshape(-1) for q in ps])
+
+    def get_optimizer_array(self, seqs=None):
+        G = self.n_global
+        pg = self.param_array[:G]
+        x = torch.where(self.positive[:G].bool(), _softplus_inv(pg), pg)
+        return torch.cat((x, self._enc_flat())).cpu().numpy()
+
+    def set_optimizer_array(self, x, seqs=None):
+        self._flush_pipeline()
+        G = self.n_global
+        x = torch.as_tensor(np.asarray(x, dtype=np.float64), device=self.device)
+        self.param_array[:G] = torch.where(self.positive[:G].bool(), _softplus(x[:G]), x[:G])
+        o = G
+        with torch.no_grad():
+            for q in self.encoder.parameters():
+                q.copy_(x[o:o + q.numel()].view_as(q))
+                o += q.numel()
+        assert o == x.numel(), 'parameter vector length mismatch'
+
+    def objective_and_grad(self, x, seqs=None):
+        """(-ELBO, -gradient) over [GP globals | encoder parameters]; with a data streamer attached and ``seqs`` None every
+        call first advances to the streamer's next minibatch (model.py:577-578,609-615)."""
+        if seqs is None and self.data_streamer is not None:
+            seqs = self._next_minibatch()
+        self.set_optimizer_array(x)
+        e = self.evaluate(seqs)
+        G = self.n_global
+        g, pg = self.grad_array[:G], self.param_array[:G]
+        g = torch.where(self.positive[:G].bool(), g * (-torch.expm1(-pg)), g)
+        out = torch.cat((g, self._enc_flat(grad=True)))
+        self.handle.sync()
+        return -float(e.item()), -out.cpu().numpy()
+
+    def save(self, path):
+        """The GP parameter vector plus every tensor of the encoder's state (the reference's ``m.param_array`` holds both)."""
+        self.handle.sync()
+        enc = {'enc__' + k: v.detach().cpu().numpy() for k, v in self.encoder.state_dict().items()}
+        np.savez(path, param_array=self.param_array.cpu().numpy(), n_global=self.n_global, n_local=self.n_local, **enc)
+
+    def load(self, path):
+        d = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        assert int(d['n_global']) == self.n_global and int(d['n_local']) == self.n_local, 'parameter layout mismatch'
+        sd = self.encoder.state_dict()
+        missing = [k for k in sd if 'enc__' + k not in d.files]
+        assert not missing, 'checkpoint holds no encoder state for: %s' % ', '.join(missing)
+        self._flush_pipeline()
+        self.param_array.copy_(torch.as_tensor(d['param_array'], device=self.device))
+        with torch.no_grad():
+            for k, v in sd.items():
+                a = torch.as_tensor(d['enc__' + k], device=v.device)
+                assert a.shape == v.shape, 'encoder tensor %s has shape %s in the checkpoint, %s in the model' % (k, tuple(a.shape), tuple(v.shape))
+                v.copy_(a)
+        self._adam = None
+        self._enc_opt = None
+
+
+class DeepAutoreg_rnn(_EncoderParamsMixin, DeepAutoreg):
     """autoreg.DeepAutoreg_rnn (model.py:284-629): q(X) of every hidden layer is produced by a recurrent encoder from the
     raw sequences (equal lengths, stacked to (T, batch, D_y + D_u) as at model.py:429), so the latents are NOT free
     parameters; the trainable parameters are the GP globals and the encoder weights.  The GP layers run through
@@ -867,7 +933,7 @@ class DeepAutoreg_rnn(DeepAutoreg):
         return elbo
 
 
-class DeepAutoreg_mlp(DeepAutoreg):
+class DeepAutoreg_mlp(_EncoderParamsMixin, DeepAutoreg):
     """autoreg.DeepAutoreg(..., back_cstr=True) (model.py:30-187 with layers.py:398-441,623-756): the predicted latent means
     of every hidden layer are the output of an MLP recursion over the layer's own past and the signal above; trainable are
     the GP globals, the first X_win latent rows, the latent variances and the MLP weights.  The GP layers run through
@@ -875,7 +941,13 @@ class DeepAutoreg_mlp(DeepAutoreg):
     (rgp_amd/mlp_encoder.py).  Sequences must have equal length (they are batched through the recursion)."""
 
     def __init__(self, wins, Y, U=None, U_win=1, nDims=None, X_variance=0.01, num_inducing=10, kernels=None,
-                 MLP_dims=None, inference_method='svi', mb_inf_tot_data_size=None, device=None, seed=0, Zs=None, **kw):
+                 MLP_dims=None, inference_method='svi', mb_inf_tot_data_size=None, device=None, seed=0, Zs=None,
+                 minibatch_inference=False, mb_inf_init_xs_means='all', mb_inf_init_xs_vars='all', mb_inf_sample_idxes=None,
+                 init_MLP_dims=None, **kw):
+        """minibatch_inference / mb_inf_init_xs_means / mb_inf_init_xs_vars: the reference's parameterisations of the
+        first rows and of the predicted rows' variances under minibatch inference (model.py:31-33,83-88; described at
+        rgp_amd.mlp_encoder.MlpBackConstraint).  All sequences of the data set are given to the constructor and stay on the
+        device; ``mb_inf_sample_idxes`` names the first minibatch, a data streamer the following ones."""
         from .mlp_encoder import MlpBackConstraint
         Ys = [Y] if isinstance(Y, np.ndarray) else list(Y)
         Us = None if U is None else ([U] if isinstance(U, np.ndarray) else list(U))
@@ -891,7 +963,18 @@ class DeepAutoreg_mlp(DeepAutoreg):
                 (int(self.lat_len[i + 1][0]) if i < self.nLayers - 1 else 0)
             specs.append(dict(index=i, X_win=L.X_win, X_dim=L.X_dim, U_win=L.U_win, U_dim=L.U_dim,
                               N=int(self.lat_len[i][0]) - L.X_win, up_len=up_len))
-        self.encoder = MlpBackConstraint(specs, self.nSeq, X_variance=X_variance, MLP_dims=MLP_dims).to(self.device)
+        low_init = None
+        if minibatch_inference and mb_inf_init_xs_means == 'mlp':               # model.py:167: first rows of the shifted observations
+            xw1 = self.layer(1).X_win
+            shift = self.U_win if Us is not None else 0                         # the model's data shift (model.py:53-69)
+            low_init = np.stack([np.asarray(y, dtype=np.float64)[shift:shift + xw1].reshape(-1) for y in Ys])
+        self.encoder = MlpBackConstraint(specs, self.nSeq, X_variance=X_variance, MLP_dims=MLP_dims,
+                                         minibatch_inference=minibatch_inference, init_xs_means=mb_inf_init_xs_means,
+                                         init_xs_vars=mb_inf_init_xs_vars, low_init=low_init,
+                                         init_MLP_dims=init_MLP_dims).to(self.device)
+        self.minibatch_inference = bool(minibatch_inference)
+        if mb_inf_sample_idxes is not None:
+            self.mb_inf_sample_idxes = [int(i) for i in mb_inf_sample_idxes]
         self.encoder.handle = self.handle                                        # the recursion runs as a device scan
         self.controls = None if Us is None else self.Ucat.view(self.nSeq, int(self.u_len[0]), self.Du)
         self._enc_index = {}
@@ -939,10 +1022,11 @@ class DeepAutoreg_mlp(DeepAutoreg):
         """One SVI step: ELBO + gradients, optional all-reduce of the replicated parameters' gradients (GP globals and MLP
         weights; the per-sequence latent parameters stay local), Adam on the GP globals (device kernel) and torch Adam on
         the recursion parameters."""
+        from .mlp_encoder import RowAdam
         if self._adam is None:
             self._init_adam()
         if self._enc_opt is None:
-            self._enc_opt = torch.optim.Adam(self.encoder.parameters(), lr=lr, maximize=True)
+            self._enc_opt = RowAdam(self.encoder)
         ad, h = self._adam, self.handle
         carry = allreduce is None and update        # single process: the next step's chains start right after the update
         self._use_chains = carry
@@ -952,7 +1036,7 @@ class DeepAutoreg_mlp(DeepAutoreg):
             self._use_chains = False
         if allreduce is not None:
             allreduce(self.grad_array[:self.n_global + 1])
-            for p in self.encoder.nets.parameters():
+            for p in self.encoder.shared_parameters():
                 allreduce(p.grad)
             elbo = self.grad_array[self.elbo_slot]
         if not update:
@@ -963,7 +1047,6 @@ class DeepAutoreg_mlp(DeepAutoreg):
                     self.positive[:G], lr, ad['t_glob'], post=carry)
         if carry:
             self._restart_chains()
-        for g in self._enc_opt.param_groups:
-            g['lr'] = lr
-        self._enc_opt.step()
+        idx = slice(None) if seqs is None else (seqs if isinstance(seqs, slice) else torch.as_tensor(list(seqs), device=self.device))
+        self._enc_opt.step(idx, lr)
         return elbo

@@ -1,4 +1,4 @@
-"""Data-parallel SVI over sequences (SURVEY.md section 8e): one process per GPU, sequences sharded, ONE all-reduce of
+"""Data-parallel SVI over sequences: one process per GPU, sequences sharded, ONE all-reduce of
 the global-gradient bucket per step.  Backend-agnostic helpers (torch.distributed: "nccl" = RCCL over xGMI on the GPU
 box, "gloo" in the CPU tests); nothing here touches the numerical path.
 

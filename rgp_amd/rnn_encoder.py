@@ -1,4 +1,4 @@
-"""Sequence-encoder back-constraint (SURVEY.md section 8f item 2): the recognition model of autoreg.DeepAutoreg_rnn
+"""Sequence-encoder back-constraint: the recognition model of autoreg.DeepAutoreg_rnn
 (/root/reference/autoreg/rnn_encoder.py:21-150, model.py:403-440,525-551).  It stays in PyTorch-ROCm as the north star
 prescribes: an fp64 stack of RNN / LSTM / GRU layers maps the raw observations (and controls) of every sequence to the
 mean and softplus-variance of each hidden layer's q(X) for ALL time steps; the GP layers then run on the device through

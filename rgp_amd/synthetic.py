@@ -1,4 +1,4 @@
-"""Synthetic workload of BASELINE.json's configs (SURVEY.md section 8d): sequences, and the reference's canonical
+"""Synthetic workload of BASELINE.json's configs: sequences, and the reference's canonical
 initialisation recipe (svi_experiments/rgp_experiments.py:632-645)."""
 import numpy as np
 

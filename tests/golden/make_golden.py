@@ -4,7 +4,7 @@
 Run (build container only -- /root/reference does not exist on the GPU box):
     python tests/golden/make_golden.py
 
-What it does (SURVEY.md Appendix B):
+What it does:
   1. writes a ~70-line stand-in for the eleven GPy symbols the reference's
      ``autoreg/inference/{vardtc,svi_vardtc}.py`` and ``autoreg/variational.py`` import
      (thin scipy.linalg.lapack wrappers + two record classes) into a temporary directory;

@@ -290,7 +290,7 @@ def test_streamer_and_checkpoint(tmp_path):
 
 
 def test_collapsed_bound_data_parallel_two_shards():
-    """Collapsed-bound data parallelism (SURVEY.md 8f item 3): two shards exchange only the sufficient statistics
+    """Collapsed-bound data parallelism: two shards exchange only the sufficient statistics
     [psi0, yry, psi2, psi1Y, PsiR] per layer (the reference's dead allReduceArrays stub, svi_vardtc.py:65-67) and one sum of
     [ELBO, global gradients] reproduces the single-device collapsed bound.  Two handles emulate the two ranks."""
     import torch

@@ -218,3 +218,29 @@ def test_config3_geometry_matches_oracle():
         num = (ep - em) / (2 * eps)
         assert abs(num - g[off + j]) <= 1e-4 * max(1.0, abs(num)), (off + j, num, g[off + j])
         off += n
+
+
+def test_checkpoint_and_lbfgs_cover_the_encoder_weights(tmp_path):
+    """save / load round-trip the encoder's tensors with the GP vector (the reference's param_array holds both,
+    examples/walk_run_2_alex.py:565-576), and the flat optimiser vector is [GP globals | encoder weights]."""
+    import torch
+    m, U, Y = build('gru')
+    for k in range(3):
+        m.svi_step(slice(0, 3), lr=1e-2)
+    e0 = float(m.evaluate().item()); m.handle.sync()
+    m.save(str(tmp_path / 'ck'))
+    torch.manual_seed(11)
+    m2, _, _ = build('gru')
+    with torch.no_grad():
+        for p in m2.encoder.parameters():
+            p.add_(torch.randn_like(p))
+    m2.load(str(tmp_path / 'ck'))
+    e1 = float(m2.evaluate().item()); m2.handle.sync()
+    assert e1 == e0
+    x0 = m2.get_optimizer_array()
+    n_enc = sum(p.numel() for p in m2.encoder.parameters())
+    assert x0.size == m2.n_global + n_enc
+    f0, g0 = m2.objective_and_grad(x0)
+    assert abs(f0 + e0) <= 1e-12 * abs(e0) and np.abs(g0[m2.n_global:]).max() > 0
+    f1, _ = m2.optimize(max_iters=5)
+    assert f1 < f0

@@ -1,5 +1,5 @@
 """Pin oracle/inference.py to the outputs of the reference's own autoreg.inference / autoreg.variational
-(fixtures made by tests/golden/make_golden.py; SURVEY.md section 8c)."""
+(fixtures made by tests/golden/make_golden.py)."""
 import glob
 import os
 

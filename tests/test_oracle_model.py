@@ -1,5 +1,5 @@
-"""Pin oracle/model.py (restated autoreg.layers / autoreg.model semantics): hand-computed window alignment
-(SURVEY.md Appendix C), scatter == the reference's per-row loop, finite-difference gradient check (the reference's
+"""Pin oracle/model.py (restated autoreg.layers / autoreg.model semantics): hand-computed window alignment,
+scatter == the reference's per-row loop, finite-difference gradient check (the reference's
 own ``checkgrad`` gate, testing/minibatch_tests.py:98-100) and additivity / permutation over minibatches
 (testing/minibatch_tests.py:281-296)."""
 import numpy as np

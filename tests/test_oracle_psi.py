@@ -1,6 +1,6 @@
 """Pin oracle/psi_stats.py: psi values against the DEFINITION (Gaussian expectations of the ARD-RBF kernel, by
 Gauss-Hermite quadrature) and every gradient against central finite differences.  GPy (where these closed forms
-live) is not under /root/reference, so this is what stands in for a reference fixture (SURVEY.md section 8c)."""
+live) is not under /root/reference, so this is what stands in for a reference fixture."""
 import itertools
 
 import numpy as np

@@ -1,4 +1,4 @@
-"""Data-streamer semantics of autoreg/data_streamers.py restated in rgp_amd/data_streamers.py (SURVEY.md 8f item 4)."""
+"""Data-streamer semantics of autoreg/data_streamers.py restated in rgp_amd/data_streamers.py."""
 import numpy as np
 
 from rgp_amd.data_streamers import RandomPermutationDataStreamer, StdMemoryDataStreamer, TrivialDataStreamer
