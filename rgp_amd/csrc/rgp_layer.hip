@@ -1222,6 +1222,18 @@ extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
 
 extern "C" rgp_status rgp_discard_prepared(rgp_handle h) {
   if (!h) return RGP_ERR_BAD_ARG;
+  // The abandoned prepares may still be running on the side streams (prep_z / chain_pre on side_pre, row work on side_rows)
+  // and no later layer step will record an event behind them.  The next user of each slot waits for ev_done[slot], so that
+  // event is recorded here behind both streams.
+  if (h->overlap) {
+    for (int k = 0; k < h->prepared_count; ++k) {
+      const int slot = h->prepared_slot[(h->prepared_head + k) % rgp_ctx::NSLOT];
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_prep, h->side_pre));
+      RGP_HIP_CHECK(h, hipStreamWaitEvent(h->side_rows, h->ev_prep, 0));
+      RGP_HIP_CHECK(h, hipEventRecord(h->ev_done[slot], h->side_rows));
+      h->done_recorded[slot] = true;
+    }
+  }
   h->prepared_count = 0;
   h->prepared_head = 0;
   return RGP_OK;

@@ -574,6 +574,8 @@ class DeepAutoreg(object):
         shares no sequence with ``seqs`` its row terms are computed while this step still runs (RGP_PREPARE_ROWS_EARLY), so the
         next step does not start with the row preparation of its first layer; a hint that turns out wrong only costs the
         prefetch (the prepared layers are discarded)."""
+        if isinstance(seqs, slice) and seqs.step not in (None, 1):
+            seqs = list(range(*seqs.indices(self.nSeq)))          # a strided slice is an index list, not a contiguous range
         if self._adam is None:
             self._init_adam()
         ad, h = self._adam, self.handle
@@ -599,19 +601,27 @@ class DeepAutoreg(object):
             h.adam_step(self.opt_array[:G], self.param_array[:G], self.grad_array[:G], ad['m'][:G], ad['v'][:G],
                         self.positive[:G], lr, ad['t_glob'])
         if isinstance(seqs, slice):
-            ranges = [(seqs.start or 0, seqs.stop if seqs.stop is not None else self.nSeq)]
+            r = range(*seqs.indices(self.nSeq))
+            ranges = [(r.start, r.stop)] if len(r) else []
         elif seqs is None:
             ranges = [(0, self.nSeq)]
         else:
             ranges = [(int(s), int(s) + 1) for s in seqs]
-        for (s0, s1) in ranges:
-            ad['t_loc'][s0:s1] += 1
-            t = int(ad['t_loc'][s0])
-            a, b = int(self.seq_loc_off[s0]), int(self.seq_loc_off[s1])
-            for base in (self.loc0, self.loc0 + self.n_local):
-                sl = slice(base + a, base + b)
-                h.adam_step(self.opt_array[sl], self.param_array[sl], self.grad_array[sl], ad['m'][sl], ad['v'][sl],
-                            self.positive[sl], lr, t)
+        for (r0, r1) in ranges:
+            ad['t_loc'][r0:r1] += 1
+            # one launch per run of sequences with the same step count (the bias correction depends on it)
+            s0 = r0
+            while s0 < r1:
+                t = int(ad['t_loc'][s0])
+                s1 = s0 + 1
+                while s1 < r1 and int(ad['t_loc'][s1]) == t:
+                    s1 += 1
+                a, b = int(self.seq_loc_off[s0]), int(self.seq_loc_off[s1])
+                for base in (self.loc0, self.loc0 + self.n_local):
+                    sl = slice(base + a, base + b)
+                    h.adam_step(self.opt_array[sl], self.param_array[sl], self.grad_array[sl], ad['m'][sl], ad['v'][sl],
+                                self.positive[sl], lr, t)
+                s0 = s1
         return elbo
 
     @staticmethod
