@@ -1598,11 +1598,23 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
       const double wsB = (bnd < 64) ? wave_sum_dpp(inA ? 0.0 : v) : 0.0;
       if (lane == 0) { wres[2 * QP] = wsA; wres[RW + 2 * QP] = wsB; }
       const int jv = lane >> 3, part = lane & 7;
+      // this thread's z values of column group k + 1 are requested before group k is worked on: a load issued at its use
+      // costs one global round trip per group, with nothing else to run in this part of the kernel
+      double zn[RED_QC];
+#pragma unroll
+      for (int j = 0; j < RED_QC; ++j) zn[j] = zrow(j);
 #pragma unroll
       for (int q0 = 0; q0 < QP; q0 += RED_QC) {
+        double zc[RED_QC];
+#pragma unroll
+        for (int j = 0; j < RED_QC; ++j) zc[j] = zn[j];
+        if (q0 + RED_QC < QP) {
+#pragma unroll
+          for (int j = 0; j < RED_QC; ++j) zn[j] = zrow(q0 + RED_QC + j);
+        }
 #pragma unroll
         for (int j = 0; j < RED_QC; ++j) {
-          const double z = zrow(q0 + j);
+          const double z = zc[j];
           wred[j * RED_RS + lane] = v * z;
           wred[(RED_QC + j) * RED_RS + lane] = 0.5 * z * (v * z + y[q0 + j]);
         }
@@ -1633,8 +1645,24 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
     STAMP(tG);
 #endif
     // dZ accumulation  d (v (2 mu - z) - y)  into the LDS slab
+    {
+      constexpr int ZB = 4;                              // same one-group-ahead requests as above
+      double zn[ZB];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) y[q] = rd[q] * (v * (2.0 * rd[QP + q] - zrow(q)) - y[q]);
+      for (int j = 0; j < ZB; ++j) zn[j] = zrow(j);
+#pragma unroll
+      for (int q0 = 0; q0 < QP; q0 += ZB) {
+        double zc[ZB];
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) zc[j] = zn[j];
+        if (q0 + ZB < QP) {
+#pragma unroll
+          for (int j = 0; j < ZB; ++j) zn[j] = zrow(q0 + ZB + j);
+        }
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) y[q0 + j] = rd[q0 + j] * (v * (2.0 * rd[QP + q0 + j] - zc[j]) - y[q0 + j]);
+      }
+    }
     STAMP(tH);
 #ifdef PSI2_DZ_PHASES
     for (int k = 0; k < NT; ++k) {
