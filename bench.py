@@ -81,6 +81,13 @@ def main():
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
+    # RGP_BENCH_FORCE_DIST=1 (debugging aid): a single rank still creates the RCCL process group and passes its all-reduce to
+    # the step, so the collective's stream handling can be exercised on a one-GPU box
+    force_dist = world == 1 and os.environ.get('RGP_BENCH_FORCE_DIST') == '1'
+    if force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local))
     if world > 1:
         if one_gpu:
             dist.init_process_group('gloo')
@@ -106,6 +113,8 @@ def main():
     if world > 1:                      # identical global parameters everywhere (q(U) init depends on local data)
         dist.broadcast(m.param_array[:m.n_global], src=0)
     allreduce = None
+    if force_dist:
+        allreduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if world > 1:
         if one_gpu:                    # gloo: CPU tensors only
             def allreduce(t):

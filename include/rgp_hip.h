@@ -116,6 +116,13 @@ rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches
  * (bit-reproducible run to run, ~23% slower at M = 100).  The environment variable RGP_PSI2_NO_PACKED=1 has the same effect. */
 rgp_status rgp_set_deterministic(rgp_handle h, int on);
 
+/* The library overlaps the M x M algebra and the row preparation with the psi passes on three streams of its own.  HIP maps
+ * all streams of a process onto a few hardware queues in creation order (GPU_MAX_HW_QUEUES), and work on one hardware queue
+ * runs in submission order, so rgp_create picks its streams by test (a kernel on the candidate must finish while a bounded
+ * spin kernel occupies the handle's stream and the streams already kept).  Returns how many of the three passed (3 = full
+ * overlap; fewer: the process has fewer free hardware queues than the library has streams, results are unaffected). */
+int        rgp_side_streams_independent(rgp_handle h);
+
 /* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,
  *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);

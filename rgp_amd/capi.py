@@ -73,6 +73,10 @@ class Handle(object):
         """Fixed summation order in the psi2 pass (bit-reproducible, slower); include/rgp_hip.h rgp_set_deterministic."""
         self._check(self.lib.rgp_set_deterministic(self.h, 1 if on else 0))
 
+    def side_streams_independent(self):
+        """How many of the library's three side streams run next to the main stream (include/rgp_hip.h)."""
+        return int(self.lib.rgp_side_streams_independent(self.h))
+
     def get_profile(self, reset=True):
         ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
         self._check(self.lib.rgp_get_profile(self.h, C.byref(ms), C.byref(n), C.byref(w), 1 if reset else 0))

@@ -72,6 +72,7 @@ struct rgp_ctx {
   char* ws_slot[NSLOT] = {};
   size_t ws_slot_bytes[NSLOT] = {};
   int slot_next = 0;                 // next slot to hand out
+  int side_streams_independent = 0;            // how many side streams were seen running next to the main stream (3 = all)
   int prepared_head = 0, prepared_count = 0;   // FIFO of slots prepared by rgp_layer_prepare
   int prepared_slot[NSLOT] = {};
   bool prepared_rows[NSLOT] = {};     // FIFO entry also has its window tables / row terms (false: chain-only prepare)

@@ -85,6 +85,61 @@ rgp_status rgp_ensure_ws(rgp_handle h, size_t bytes) {
 
 extern "C" int rgp_abi_version(void) { return 1; }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Side streams that really run next to the main stream.  HIP multiplexes all streams of a process onto a few hardware
+// queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and packets of one hardware queue execute in submission order.
+// A process that has created other streams first (an RCCL communicator makes six) can therefore hand this library a side
+// stream that shares the main stream's queue: the M x M chain of the next step then sits in front of the next layer's psi
+// passes and the step serialises (measured: 2.9 -> 6.2 ms per step at 4 sequences per rank).  So the streams are picked by
+// test: a candidate is kept if a kernel launched on it finishes while a bounded spin kernel still occupies the main stream
+// and every stream kept so far.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) stream_probe_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();                  // constant-rate counter (100 MHz): the loop ends after `ticks`
+  while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void __launch_bounds__(64) stream_probe_noop_kernel() {}
+
+static bool streams_run_side_by_side(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec) {
+  hipLaunchKernelGGL(stream_probe_spin_kernel, dim3(1), dim3(64), 0, busy, 30000LL);      // ~300 us
+  (void)hipEventRecord(eb, busy);
+  hipLaunchKernelGGL(stream_probe_noop_kernel, dim3(1), dim3(64), 0, cand);
+  (void)hipEventRecord(ec, cand);
+  (void)hipEventSynchronize(ec);
+  const bool side_by_side = hipEventQuery(eb) == hipErrorNotReady;
+  (void)hipGetLastError();                              // hipErrorNotReady is sticky for hipGetLastError
+  (void)hipEventSynchronize(eb);
+  return side_by_side;
+}
+
+// Fills side[0..2]; returns how many of them passed the test against the main stream and each other (3 = all).
+static int pick_side_streams(hipStream_t main_stream, hipStream_t side[3]) {
+  const bool probe = getenv("RGP_NO_STREAM_PROBE") == nullptr;
+  hipEvent_t eb, ec;
+  (void)hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&ec, hipEventDisableTiming);
+  hipStream_t rejected[16];
+  int n_ok = 0, n_rej = 0;
+  for (int tries = 0; n_ok < 3 && tries < 16; ++tries) {
+    hipStream_t c = nullptr;
+    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+    bool ok = true;
+    if (probe) {
+      hipLaunchKernelGGL(stream_probe_noop_kernel, dim3(1), dim3(64), 0, c);     // the stream's queue exists before the test
+      (void)hipStreamSynchronize(c);
+      ok = streams_run_side_by_side(main_stream, c, eb, ec);
+      for (int k = 0; ok && k < n_ok; ++k) ok = streams_run_side_by_side(side[k], c, eb, ec);
+    }
+    if (ok) side[n_ok++] = c; else rejected[n_rej++] = c;
+  }
+  const int passed = n_ok;
+  while (n_ok < 3 && n_rej > 0) side[n_ok++] = rejected[--n_rej];               // fewer hardware queues than streams: share
+  while (n_rej > 0) (void)hipStreamDestroy(rejected[--n_rej]);
+  (void)hipEventDestroy(eb);
+  (void)hipEventDestroy(ec);
+  return n_ok == 3 ? passed : -1;
+}
+
 extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) {
   if (!out) return RGP_ERR_BAD_ARG;
   rgp_ctx* h = new rgp_ctx();
@@ -97,9 +152,12 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
   h->overlap = getenv("RGP_NO_OVERLAP") == nullptr;
-  if (hipStreamCreateWithFlags(&h->side_pre, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->side_post, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->side_rows, hipStreamNonBlocking) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  {
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    h->side_streams_independent = pick_side_streams(h->stream, side);
+    if (h->side_streams_independent < 0) { delete h; return RGP_ERR_HIP; }
+    h->side_pre = side[0]; h->side_post = side[1]; h->side_rows = side[2];
+  }
   hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_post_pos, hipEventDisableTiming);
   hipEventCreateWithFlags(&h->ev_post_tail, hipEventDisableTiming);
@@ -152,6 +210,8 @@ extern "C" rgp_status rgp_sync_status(rgp_handle h, int* pivot) {
   }
   return RGP_OK;
 }
+
+extern "C" int rgp_side_streams_independent(rgp_handle h) { return h ? h->side_streams_independent : -1; }
 
 extern "C" rgp_status rgp_set_deterministic(rgp_handle h, int on) {
   if (!h) return RGP_ERR_BAD_ARG;

@@ -80,3 +80,17 @@ def test_two_ranks_track_the_single_process_run(tmp_path, lazy, single_bucket):
     m.handle.sync()
     np.testing.assert_allclose(got['e'], np.array(elbos), rtol=1e-10)
     np.testing.assert_allclose(got['g'], m.param_array[:m.n_global].cpu().numpy(), rtol=1e-8, atol=1e-10)
+
+
+def test_side_streams_keep_their_own_hardware_queues_after_other_streams_exist():
+    """A process that created many streams before the handle (an RCCL communicator makes six) must still get side streams that
+    run next to the main stream: rgp_create picks them by test, not by creation order."""
+    import torch
+    from rgp_amd.capi import Handle
+    hold = [torch.cuda.Stream() for _ in range(6)]
+    for s in hold:
+        with torch.cuda.stream(s):
+            torch.zeros(8, device='cuda')
+    torch.cuda.synchronize()
+    h = Handle()
+    assert h.side_streams_independent() == 3
