@@ -27,6 +27,9 @@
 #ifndef BF_RT
 #define BF_RT 16
 #endif
+#ifndef BIG_BWD_SYNC_EVERY
+#define BIG_BWD_SYNC_EVERY 0      // power of two (inducing columns between two meetings of the workgroup's waves), 0 = never
+#endif
 #ifndef BF_NP
 #define BF_NP 2           // inducing columns per lane for padded Q <= 48 (1: half the registers, four waves per SIMD)
 #endif
@@ -494,6 +497,12 @@ big_psi2_bwd_kernel(const int64_t N, const int M, const int IB, const int TS, co
 #pragma unroll
       for (int u = 0; u < 4; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
       for (int mp = 0; mp < M; mp += 4) {
+#if BIG_BWD_SYNC_EVERY > 0
+        // The eight waves of the workgroup read the same z[m',:] rows as scalar operands.  Left alone they drift apart by more
+        // rows than the 16 KB scalar cache holds (Z is 160 KB at M = 500) and each wave fetches its rows from L2 again;
+        // meeting every few rows keeps them within one cache-full of each other.
+        if ((mp & (BIG_BWD_SYNC_EVERY - 1)) == 0) __syncthreads();
+#endif
         double dlc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -1733,12 +1733,484 @@ psi2_rowsN_kernel(const int64_t N, const int M, const int Q, const int NT, const
 }
 #undef zrow
 
+// ------------------------------------------------------------------------------------------------------------------
+// The packed-team pass with its waves in two roles, half a step apart.
+//   The sweep of psi2_rowsN_kernel issues at the rate of the fp64 pipe; the rest of an iteration (row reductions, dZ update,
+//   next row's operands) is a third of its time and is bound by latencies -- LDS round trips, uncoalesced loads of the thread's
+//   z row, four workgroup barriers that hold all eight waves in the same phase.  Here each SIMD's two waves take different
+//   roles: role 0 runs [sweep(k), pass(k), barrier], role 1 runs [sweep(k), barrier, pass(k)], where pass(k) is everything
+//   between two sweeps.  One barrier per iteration, and it releases role 0 into sweep(k+1) while role 1 does pass(k): from then
+//   on a SIMD always has one wave in the sweep while the other is in its pass (a single wave issues an fp64 multiply-add every
+//   ~6 cycles, two share the pipe at ~5).  What a wave publishes for the others goes through rings deep enough for the
+//   half-step offset (b_k = the barrier of iteration k):
+//     h values of a row's sweep   hb(k+1): role 0 in pass(k), before b_k; role 1 computes hb(k+2) in pass(k), after b_k;
+//                                 read in sweep(k+1), after b_k; two slots
+//     row operands                rowd(k+2) written by role 0 in pass(k), rowd(k+3) by role 1; last read by the row-gradient
+//                                 threads of iteration k two barriers later; five slots
+//     per-wave partial row sums   wres(k) written in pass(k), combined into the row gradients of iteration k by role 0 in
+//                                 pass(k+2) and by role 1 in pass(k+1) -- both between b_{k+1} and b_{k+2}; three slots
+//   pass(k) reads the thread's z row ONCE: reductions and dZ update of iteration k, then dzl and h of the coming rows, column
+//   group by column group (the y registers of a column are dead when its dzl is written).
+//   Roles are handed out by SIMD (hardware id register + an LDS ticket), so the two waves of a SIMD never share one.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef PSI2_PRIO_PASS
+#define PSI2_PRIO_PASS 3        // issue priority (s_setprio) of a wave between two sweeps, -1: leave priorities alone
+#endif
+#ifndef PSI2_PRIO_SWEEP0
+#define PSI2_PRIO_SWEEP0 1      // ... of a role-0 wave in the sweep (pass/sweep0/sweep1 = 3/1/0: 56.4, 3/0/0: 56.0, 3/0/1 and 3/0/2: 54.5 steps/s)
+#endif
+#ifndef PSI2_PRIO_SWEEP1
+#define PSI2_PRIO_SWEEP1 0      // ... of a role-1 wave in the sweep
+#endif
+#define PSI2_RING_ROWD 5
+#define PSI2_RING_RES 3
+
+typedef __attribute__((address_space(1))) double gdouble;
+
+// Wave-uniform values that only the code between two sweeps needs are parked in the lanes of one VGPR and read back with
+// v_readlane after every sweep: the sweep keeps z[m',:] of the pair in work in 80 of the ~100 SGPRs, and every scalar that is
+// live across it is spilled and reloaded inside the pair loop by the register allocator (72 extra instructions per pair).
+enum { PK_M, PK_Q, PK_NT, PK_TS, PK_ACC, PK_BND, PK_R0, PK_R0H, PK_R1, PK_R1H, PK_XMU, PK_XMUH, PK_D2, PK_D2H, PK_G0, PK_G0H,
+       PK_GMU, PK_GMUH, PK_GS, PK_GSH, PK_P2, PK_P2H, PK_DZ, PK_DZH, PK_DLAM, PK_DLAMH, PK_WSUM, PK_WSUMH, PK_K, PK_ROLE };
+static __device__ __forceinline__ int pk_put(int pk, const int idx, int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(pk) : "s"(v), "n"(idx));
+  return pk;
+}
+static __device__ __forceinline__ int pk_putp(int pk, int idx, const void* p) {
+  const unsigned long long u = (unsigned long long)p;
+  return pk_put(pk_put(pk, idx, (int)(unsigned)u), idx + 1, (int)(unsigned)(u >> 32));
+}
+static __device__ __forceinline__ int pk_get(int pk, int idx) { return __builtin_amdgcn_readlane(pk, idx); }
+static __device__ __forceinline__ long long pk_get64(int pk, int idx) {
+  return (long long)(((unsigned long long)(unsigned)pk_get(pk, idx + 1) << 32) | (unsigned)pk_get(pk, idx));
+}
+static __device__ __forceinline__ gdouble* pk_getp(int pk, int idx) { return (gdouble*)pk_get64(pk, idx); }
+
+template <int QP, int QC>
+__global__ void __launch_bounds__(PSI2_T4, 2)
+psi2_rowsP_kernel(const int64_t N, const int64_t per, const int M, const int Q, const int NT, const int TS,
+                  const double* __restrict__ Zc, const double* __restrict__ lam_g, const double* __restrict__ dLs_g,
+                  const double* __restrict__ Xmu_g, const double* __restrict__ d2_g, const double* __restrict__ g0_g,
+                  double* __restrict__ p2_part, double* __restrict__ dz_part, double* __restrict__ dlam_part,
+                  double* __restrict__ wsum_part, double* __restrict__ gmu_g, double* __restrict__ gS_g,
+                  const int accumulate, double* dbgout) {
+  extern __shared__ double lds[];
+  constexpr int RW = 2 * QP + 2;                          // a1[QP] | a23[QP] | w | pad
+  constexpr int RD = 2 * QP + 2;                          // staged row: d2[QP] | mu[QP] | g0 | pad
+  constexpr int NV = 2 * QC;                              // value rows of one transposition
+  constexpr int G = 64 / NV;                              // lanes that share one value row
+  constexpr int RS = (QC == 4) ? 72 : 80;                 // row stride of the transposition scratch: the value rows a 32-lane
+                                                          // group reads fall into disjoint banks
+  __shared__ int simd_cnt[4];
+  // LDS map (doubles): p2acc [tri] | dzacc [QP x DZS] | hbuf [2][NT x TS] | rowd [5][NT x RD] | red [8 waves][NV x RS] |
+  //                    res [3][8 waves x 2 x RW] | etab [256] | lamL [QP]
+#define P2_TRI(M_) ((M_) * ((M_) + 1) / 2)
+#define P2_DZS(M_) (((M_) + 3) & ~3)
+#define P2_DZACC(M_) (lds + P2_TRI(M_))
+#define P2_HBUF(M_) (P2_DZACC(M_) + QP * P2_DZS(M_))
+#define P2_ROWD(M_, NT_, TS_) (P2_HBUF(M_) + 2 * (NT_) * (TS_))
+#define P2_RED(M_, NT_, TS_) (P2_ROWD(M_, NT_, TS_) + PSI2_RING_ROWD * (NT_) * RD)
+#define P2_RES(M_, NT_, TS_) (P2_RED(M_, NT_, TS_) + 8 * NV * RS)
+#define P2_ETAB(M_, NT_, TS_) (P2_RES(M_, NT_, TS_) + PSI2_RING_RES * 8 * 2 * RW)
+#define P2_LAM(M_, NT_, TS_) (P2_ETAB(M_, NT_, TS_) + PSI2_EXP_TAB)
+
+  const int t = threadIdx.x;
+  const int team_raw = t / TS;
+  const int tr_raw = t - team_raw * TS;
+  int pk = 0;
+  double ellq = 0.0;
+  int K;
+  int role;
+  double dzl[QP];
+  double base;
+  const double* __restrict__ zrowp;
+#define zrow(q) zrowp[q]
+  {
+    const int wave = t >> 6, lane = t & 63;
+    const bool act = team_raw < NT && tr_raw < M;
+    const int team = team_raw < NT ? team_raw : NT - 1;
+    const int tr = act ? tr_raw : M - 1;
+    zrowp = Zc + (size_t)tr * QP;
+    const int tri = P2_TRI(M);
+    double* p2acc = lds;
+    double* dzacc = P2_DZACC(M);
+    double* hbuf = P2_HBUF(M);
+    double* rowd = P2_ROWD(M, NT, TS);
+    double* etab = P2_ETAB(M, NT, TS);
+    double* lamL = P2_LAM(M, NT, TS);
+    for (int i = t; i < tri; i += PSI2_T4) p2acc[i] = 0.0;
+    for (int i = t; i < QP * P2_DZS(M); i += PSI2_T4) dzacc[i] = 0.0;
+    if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
+    if (t < QP) lamL[t] = lam_g[t];
+    if (t < 4) simd_cnt[t] = 0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) ellq += 0.25 * lam_g[q] * zrow(q) * zrow(q);
+
+    const int64_t r0 = (int64_t)blockIdx.x * per;
+    const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+    K = (r1 > r0) ? (int)((r1 - r0 + NT - 1) / NT) : 0;     // iterations of this workgroup, the same for all its waves
+    const int ta = (64 * wave) / TS;
+    const int bnd = ((ta + 1) * TS - 64 * wave < 64) ? (ta + 1) * TS - 64 * wave : 64;
+
+    // operands of the first three iterations
+    for (int k = 0; k < 3; ++k) {
+      for (int e = t; e < NT * RD; e += PSI2_T4) {
+        const int sk = e / RD, sj = e - sk * RD;
+        int64_t nk = r0 + (int64_t)k * NT + sk;
+        nk = (nk < r1) ? nk : r1 - 1;
+        nk = (nk < 0) ? 0 : nk;
+        rowd[k * NT * RD + e] = (sj < QP) ? d2_g[nk * QP + sj] : (sj < 2 * QP) ? Xmu_g[nk * QP + (sj - QP)] : (sj == 2 * QP) ? g0_g[nk] : 0.0;
+      }
+    }
+    __syncthreads();
+    // role of this wave: the two waves of a SIMD draw tickets 0 and 1
+    {
+      const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3u;      // HW_ID bits [5:4]
+      int tk = 0;
+      if (lane == 0) tk = atomicAdd(&simd_cnt[simd], 1);
+      role = __builtin_amdgcn_readfirstlane(tk) & 1;
+      if (dbgout && lane == 0) dbgout[blockIdx.x * 8 + wave] = (double)(simd * 10 + role);
+    }
+    pk = pk_put(pk, PK_M, M); pk = pk_put(pk, PK_Q, Q); pk = pk_put(pk, PK_NT, NT); pk = pk_put(pk, PK_TS, TS);
+    pk = pk_put(pk, PK_ACC, accumulate); pk = pk_put(pk, PK_BND, bnd);
+    pk = pk_putp(pk, PK_R0, (const void*)r0); pk = pk_putp(pk, PK_R1, (const void*)r1);
+    pk = pk_putp(pk, PK_XMU, Xmu_g); pk = pk_putp(pk, PK_D2, d2_g); pk = pk_putp(pk, PK_G0, g0_g);
+    pk = pk_putp(pk, PK_GMU, gmu_g); pk = pk_putp(pk, PK_GS, gS_g);
+    pk = pk_putp(pk, PK_P2, p2_part); pk = pk_putp(pk, PK_DZ, dz_part); pk = pk_putp(pk, PK_DLAM, dlam_part);
+    pk = pk_putp(pk, PK_WSUM, wsum_part);
+    pk = pk_put(pk, PK_K, K); pk = pk_put(pk, PK_ROLE, role);
+
+    const double* rd = rowd + team * RD;
+    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; q += 2) {
+      const double z0 = zrow(q), z1 = zrow(q + 1);
+      const double d0 = rd[q], d1 = rd[q + 1];
+      dzl[q] = -0.5 * z0 * (d0 - lam_g[q]);
+      dzl[q + 1] = -0.5 * z1 * (d1 - lam_g[q + 1]);
+      h0 += z0 * d0 * (rd[QP + q] - 0.25 * z0);
+      h1 += z1 * d1 * (rd[QP + q + 1] - 0.25 * z1);
+    }
+    const double h = (h0 + h1) - ellq;
+    if (act) hbuf[team * TS + tr] = h;
+    base = (act && r0 + team < r1) ? (rd[2 * QP] + h) : -INFINITY;
+    if (role) {
+      const double* rh = rowd + NT * RD + team * RD;
+      double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < QP; q += 2) {
+        const double z0 = zrow(q), z1 = zrow(q + 1);
+        g0 += z0 * rh[q] * (rh[QP + q] - 0.25 * z0);
+        g1 += z1 * rh[q + 1] * (rh[QP + q + 1] - 0.25 * z1);
+      }
+      if (act) hbuf[NT * TS + team * TS + tr] = (g0 + g1) - ellq;
+    }
+    __syncthreads();
+  }
+
+  // thread state that lives through the sweeps (VGPRs): t, team_raw, tr_raw, zrowp, ellq, pk, the two sums below
+  double dlam_acc = 0.0, wsum_acc = 0.0;
+
+  // row gradients of iteration j: thread (team, q) combines the wave partials that cover its team, in wave order
+  auto rowgrad = [&](const int pkv, const int j, const double g_old_mu, const double g_old_S) {
+    const int M_ = pk_get(pkv, PK_M), Q_ = pk_get(pkv, PK_Q), NT_ = pk_get(pkv, PK_NT), TS_ = pk_get(pkv, PK_TS);
+    const int64_t r0 = pk_get64(pkv, PK_R0), r1 = pk_get64(pkv, PK_R1);
+    const int team = team_raw < NT_ ? team_raw : NT_ - 1;
+    const int64_t n = r0 + (int64_t)j * NT_ + team;
+    if (!(team_raw < NT_ && tr_raw < QP) || n >= r1) return;
+    gdouble* gmu = pk_getp(pkv, PK_GMU);
+    gdouble* gS = pk_getp(pkv, PK_GS);
+    const int q = tr_raw;
+    if (q < Q_) {
+      const double* rj = P2_ROWD(M_, NT_, TS_) + (j % PSI2_RING_ROWD) * NT_ * RD + team * RD;
+      const double* resj = P2_RES(M_, NT_, TS_) + (size_t)(j % PSI2_RING_RES) * 8 * 2 * RW;
+      const int w0 = (team * TS_) >> 6, w1 = (team * TS_ + M_ - 1) >> 6;
+      double w = 0.0, a1 = 0.0, a23 = 0.0;
+      for (int wv = w0; wv <= w1; ++wv) {
+        const int slot = ((64 * wv) / TS_ == team) ? 0 : 1;
+        const double* tres = resj + ((size_t)wv * 2 + slot) * RW;
+        w += tres[2 * QP];
+        a1 += tres[q];
+        a23 += tres[QP + q];
+      }
+      const double mu = rj[QP + q], dq = rj[q];
+      const double dmu = 2.0 * dq * (a1 - mu * w);
+      const double dd = -mu * mu * w + 2.0 * mu * a1 - a23 + 0.5 * w / dq;
+      const double dS = -2.0 * dq * dq * dd;
+      gmu[n * QP + q] = g_old_mu + dmu;
+      gS[n * QP + q] = g_old_S + dS;
+      const double il = 1.0 / P2_LAM(M_, NT_, TS_)[q];
+      dlam_acc += dd * (dq * il) * (dq * il) - 0.5 * w * il;
+      if (q == 0) wsum_acc += w;
+    } else if (!pk_get(pkv, PK_ACC)) {
+      gmu[n * QP + q] = 0.0;
+      gS[n * QP + q] = 0.0;
+    }
+  };
+  auto g_old_load = [&](const int pkv, const int j, double& gm, double& gs) {
+    gm = 0.0; gs = 0.0;
+    const int NT_ = pk_get(pkv, PK_NT);
+    if (j < 0 || !pk_get(pkv, PK_ACC) || !(team_raw < NT_ && tr_raw < QP) || tr_raw >= pk_get(pkv, PK_Q)) return;
+    const int team = team_raw < NT_ ? team_raw : NT_ - 1;
+    const int64_t n = pk_get64(pkv, PK_R0) + (int64_t)j * NT_ + team;
+    if (n >= pk_get64(pkv, PK_R1)) return;
+    gm = pk_getp(pkv, PK_GMU)[n * QP + tr_raw];
+    gs = pk_getp(pkv, PK_GS)[n * QP + tr_raw];
+  };
+
+#ifdef PSI2_STAMPS
+  long long tS = 0, tP = 0, tW = 0, tH = 0, t0 = 0, t1;
+#endif
+  for (int k = 0; k < K; ++k) {
+    asm volatile("" ::: "memory");
+#ifdef PSI2_STAMPS
+    t0 = __builtin_readcyclecounter();
+#endif
+    double y[QP];
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < QP; ++q) y[q] = 0.0;
+    {
+      const bool act = team_raw < NT && tr_raw < M;
+      const int team = team_raw < NT ? team_raw : NT - 1;
+      const int tr = act ? tr_raw : M - 1;
+      const int tr_own = act ? tr : 0x7fffffff;
+      const double* __restrict__ dlrow = dLs_g + tr;
+      double* p2acc = lds;
+      const double* etab = P2_ETAB(M, NT, TS);
+      const double* hb = P2_HBUF(M) + (k & 1) * NT * TS + team * TS;
+      const int last = M - 1;
+      double dlv[PSI2_UNR];
+#pragma unroll
+      for (int u = 0; u < PSI2_UNR; ++u) dlv[u] = dlrow[(size_t)((u < M) ? u : last) * M];
+      for (int mp = 0; mp < M; mp += PSI2_UNR) {
+#ifdef PSI2_STAMPS
+        if (mp == ((M / 2) & ~(PSI2_UNR - 1))) { t1 = __builtin_readcyclecounter(); tH += t1 - t0; }
+#endif
+        double dlc[PSI2_UNR];
+#pragma unroll
+        for (int u = 0; u < PSI2_UNR; ++u) {
+          dlc[u] = dlv[u];
+          dlv[u] = dlrow[(size_t)((mp + PSI2_UNR + u < M) ? mp + PSI2_UNR + u : last) * M];
+        }
+#pragma unroll
+        for (int u = 0; u < PSI2_UNR; ++u) {
+          const int mq = mp + u;
+          if (u == 0 || mq < M)
+            psi2_pair_fix<QP>(Zc + (size_t)mq * QP, dzl, y, v, base, hb[mq], dlc[u], p2acc + (mq * (mq + 1) / 2 + tr),
+                              mq >= tr_own, etab);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    STAMP(tS);
+    if (role) __syncthreads();                          // b_k for role 1: the others have published what its pass reads
+    STAMP(tW);
+
+    // pass(k): every wave-uniform value is read back from the parked register
+    {
+#if PSI2_PRIO_PASS >= 0
+      __builtin_amdgcn_s_setprio(PSI2_PRIO_PASS);
+#endif
+      int pkv = pk;
+      asm volatile("" : "+v"(pkv));
+      int tv = t, teamv = team_raw, trv = tr_raw;
+      asm volatile("" : "+v"(tv), "+v"(teamv), "+v"(trv));
+      const int M_ = pk_get(pkv, PK_M), NT_ = pk_get(pkv, PK_NT), TS_ = pk_get(pkv, PK_TS), bnd = pk_get(pkv, PK_BND);
+      const int role_ = pk_get(pkv, PK_ROLE), K_ = pk_get(pkv, PK_K);
+      const int64_t r0 = pk_get64(pkv, PK_R0), r1 = pk_get64(pkv, PK_R1);
+      const int hoff = 1 + role_;                         // role 1 computes h one iteration further ahead
+      const int ks = k + 2 + role_;                       // and stages row operands one iteration further ahead
+      const int jr = k - 2 + role_;
+      const int wave = tv >> 6, lane = tv & 63;
+      const bool act = teamv < NT_ && trv < M_;
+      const int team = teamv < NT_ ? teamv : NT_ - 1;
+      const int tr = act ? trv : M_ - 1;
+      const bool inA = lane < bnd;
+      const int DZS = P2_DZS(M_);
+      double* dzacc = P2_DZACC(M_);
+      double* hbuf = P2_HBUF(M_);
+      double* rowd = P2_ROWD(M_, NT_, TS_);
+      const double* lamL = P2_LAM(M_, NT_, TS_);
+
+      // loads whose latency hides under this pass: row operands of a later iteration, gradient slots of an earlier one
+      const bool do_stage = ks >= 3 && ks < K_;
+      const bool stager = tv < NT_ * RD, stager2 = tv + PSI2_T4 < NT_ * RD;
+      double staged = 0.0, staged2 = 0.0;
+      if (do_stage) {
+        gdouble* Xmu_p = pk_getp(pkv, PK_XMU);
+        gdouble* d2_p = pk_getp(pkv, PK_D2);
+        gdouble* g0_p = pk_getp(pkv, PK_G0);
+        auto stage_load = [&](int e) -> double {
+          const int sk = e / RD, sj = e - sk * RD;
+          int64_t nk = r0 + (int64_t)ks * NT_ + sk;
+          nk = (nk < r1) ? nk : r1 - 1;
+          if (sj < QP) return d2_p[nk * QP + sj];
+          if (sj < 2 * QP) return Xmu_p[nk * QP + (sj - QP)];
+          if (sj == 2 * QP) return g0_p[nk];
+          return 0.0;
+        };
+        if (stager) staged = stage_load(tv);
+        if (stager2) staged2 = stage_load(tv + PSI2_T4);
+      }
+      double g_old_mu, g_old_S;
+      g_old_load(pkv, jr, g_old_mu, g_old_S);
+
+      const double* rk = rowd + (k % PSI2_RING_ROWD) * NT_ * RD + team * RD;
+      const double* rn = rowd + ((k + 1) % PSI2_RING_ROWD) * NT_ * RD + team * RD;
+      const double* rh = rowd + ((k + hoff) % PSI2_RING_ROWD) * NT_ * RD + team * RD;
+      double* wres = P2_RES(M_, NT_, TS_) + ((size_t)(k % PSI2_RING_RES) * 8 + wave) * 2 * RW;
+      double* wred = P2_RED(M_, NT_, TS_) + wave * NV * RS;
+      const double wsA = wave_sum_dpp(inA ? v : 0.0);
+      const double wsB = (bnd < 64) ? wave_sum_dpp(inA ? 0.0 : v) : 0.0;
+      if (lane == 0) { wres[2 * QP] = wsA; wres[RW + 2 * QP] = wsB; }
+      const int jv = lane / G, part = lane % G;
+      // lanes without an inducing row add 0.0 to a slot of their own (no branch around the atomic: a chunk stays one
+      // basic block, so its LDS reads are issued together and not one round trip after the other)
+      const int trz = act ? tr : (trv % M_);
+      double* dzp = dzacc + trz;
+      // the eight (or sixteen) lanes that hold the finished sums of a value row store them; the other lanes store into the
+      // transposition scratch, which the next chunk overwrites
+      double h0 = 0.0, h1 = 0.0;
+      double zn[QC];
+#pragma unroll
+      for (int j = 0; j < QC; ++j) zn[j] = zrow(j);
+#pragma unroll
+      for (int q0 = 0; q0 < QP; q0 += QC) {
+        double zc[QC];
+#pragma unroll
+        for (int j = 0; j < QC; ++j) zc[j] = zn[j];
+        if (q0 + QC < QP) {
+#pragma unroll
+          for (int j = 0; j < QC; ++j) zn[j] = zrow(q0 + QC + j);
+        }
+        asm volatile("" ::: "memory");                  // one column group of loads in flight, not all of them
+        // row operands of the chunk's columns, all requested before anything waits for one of them
+        double dk[QC], mk[QC], dn[QC], dh[QC], mh[QC], lm[QC];
+#pragma unroll
+        for (int j = 0; j < QC; ++j) {
+          const int q = q0 + j;
+          dk[j] = rk[q]; mk[j] = rk[QP + q]; dn[j] = rn[q]; dh[j] = rh[q]; mh[j] = rh[QP + q]; lm[j] = lamL[q];
+        }
+#pragma unroll
+        for (int j = 0; j < QC; ++j) {
+          const double z = zc[j];
+          wred[j * RS + lane] = v * z;
+          wred[(QC + j) * RS + lane] = 0.5 * z * (v * z + y[q0 + j]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        double x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) x[i] = wred[jv * RS + part + G * i];
+        __builtin_amdgcn_wave_barrier();
+        // dZ update of iteration k, then the coming rows' dzl and h for these columns
+#pragma unroll
+        for (int j = 0; j < QC; ++j) {
+          const int q = q0 + j;
+          const double z = zc[j];
+          const double dzv = dk[j] * (v * (2.0 * mk[j] - z) - y[q]);
+          atomicAdd(dzp + q * DZS, act ? dzv : 0.0);
+          dzl[q] = -0.5 * z * (dn[j] - lm[j]);
+          const double hz = z * dh[j] * (mh[j] - 0.25 * z);
+          if (j & 1) h1 += hz; else h0 += hz;
+          asm volatile("" : "+v"(dzl[q]));              // computed here, not sunk to the end of the pass with its operands spilled
+        }
+        asm volatile("" : "+v"(h0), "+v"(h1));
+        double sA = 0.0, sB = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const bool a = part + G * i < bnd;
+          sA += a ? x[i] : 0.0;
+          sB += a ? 0.0 : x[i];
+        }
+        sA = sum8_dpp(sA);
+        if (G == 16) sA += dpp_f64<0x140>(sA);
+        if (bnd < 64) {
+          sB = sum8_dpp(sB);
+          if (G == 16) sB += dpp_f64<0x140>(sB);
+        }
+        {
+          const int o = (jv < QC ? 0 : QP) + q0 + (jv % QC);
+          double* pa = (part == 0) ? wres + o : wred + lane;
+          double* pb = (part == 0) ? wres + RW + o : wred + RS + lane;
+          *pa = sA;
+          *pb = sB;
+        }
+      }
+      if (act) hbuf[((k + hoff) & 1) * NT_ * TS_ + team * TS_ + tr] = (h0 + h1) - ellq;
+      const double hn = hbuf[((k + 1) & 1) * NT_ * TS_ + team * TS_ + tr];      // this thread's own value (role 1: from its last pass)
+      base = (act && r0 + (int64_t)(k + 1) * NT_ + team < r1) ? (rn[2 * QP] + hn) : -INFINITY;
+      if (do_stage) {
+        double* rs = rowd + (ks % PSI2_RING_ROWD) * NT_ * RD;
+        if (stager) rs[tv] = staged;
+        if (stager2) rs[tv + PSI2_T4] = staged2;
+      }
+      if (jr >= 0) rowgrad(pkv, jr, g_old_mu, g_old_S);
+#if PSI2_PRIO_PASS >= 0
+      if (role) __builtin_amdgcn_s_setprio(PSI2_PRIO_SWEEP1); else __builtin_amdgcn_s_setprio(PSI2_PRIO_SWEEP0);
+#endif
+    }
+    STAMP(tP);
+    if (!role) __syncthreads();                         // b_k for role 0
+    STAMP(tW);
+  }
+  __syncthreads();                                      // the last passes of role 1 are done
+#ifdef PSI2_STAMPS
+  if (dbgout && (t & 63) == 0) {
+    double* o = dbgout + 2048 + (blockIdx.x * 8 + (t >> 6)) * 4;
+    o[0] = (double)tS; o[1] = (double)tP; o[2] = (double)tW; o[3] = (double)K; dbgout[2048 + 256 * 8 * 4 + blockIdx.x * 8 + (t >> 6)] = (double)tH;
+  }
+#endif
+  {
+    int pkv = pk;
+    asm volatile("" : "+v"(pkv));
+    const int role_ = pk_get(pkv, PK_ROLE), K_ = pk_get(pkv, PK_K);
+    for (int j = (K_ - 2 + role_ > 0 ? K_ - 2 + role_ : 0); j < K_; ++j) {
+      double gm, gs;
+      g_old_load(pkv, j, gm, gs);
+      rowgrad(pkv, j, gm, gs);
+    }
+    const int M_ = pk_get(pkv, PK_M), NT_ = pk_get(pkv, PK_NT), Q_ = pk_get(pkv, PK_Q);
+    const int tri = P2_TRI(M_), DZS = P2_DZS(M_);
+    const double* p2acc = lds;
+    const double* dzacc = P2_DZACC(M_);
+    gdouble* out = pk_getp(pkv, PK_P2) + (size_t)blockIdx.x * tri;
+    for (int i = t; i < tri; i += PSI2_T4) out[i] = p2acc[i];
+    gdouble* outz = pk_getp(pkv, PK_DZ) + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM;
+    for (int i = t; i < QP * RGP_PSI2_TEAM; i += PSI2_T4) {
+      const int q = i / RGP_PSI2_TEAM, m = i - q * RGP_PSI2_TEAM;
+      outz[i] = (m < M_) ? dzacc[q * DZS + m] : 0.0;
+    }
+    const int team = team_raw < NT_ ? team_raw : NT_ - 1;
+    if (team_raw < NT_ && tr_raw < QP) pk_getp(pkv, PK_DLAM)[((size_t)blockIdx.x * NT_ + team) * QP + tr_raw] = (tr_raw < Q_) ? dlam_acc : 0.0;
+    if (team_raw < NT_ && tr_raw == 0) pk_getp(pkv, PK_WSUM)[(size_t)blockIdx.x * NT_ + team] = wsum_acc;
+  }
+}
+#undef zrow
+
 static int psi2_team_stride(int M) { return M < 64 ? 64 : M; }
 
 static size_t psi2_rowsN_lds(int M, int QP, int NT) {
   const size_t tri = (size_t)M * (M + 1) / 2;
   return (tri + (size_t)QP * RGP_PSI2_TEAM + (size_t)NT * RGP_PSI2_TEAM + (size_t)NT * (2 * (size_t)QP + 2) +
           8 * RED_WAVE + 8 * 2 * (2 * (size_t)QP + 8) + PSI2_EXP_TAB) * sizeof(double);
+}
+
+// LDS bytes of the two-role kernel for QC columns per reduction chunk (0: the shape does not fit)
+static size_t psi2_rowsP_lds(int M, int QP, int NT, int QC) {
+  const size_t tri = (size_t)M * (M + 1) / 2, ts = psi2_team_stride(M), dzs = (M + 3) & ~3, rw = 2 * (size_t)QP + 2;
+  const size_t n = tri + QP * dzs + 2 * NT * ts + PSI2_RING_ROWD * NT * rw + 8 * (2 * (size_t)QC) * (QC == 4 ? 72 : 80) +
+                   PSI2_RING_RES * 8 * 2 * rw + PSI2_EXP_TAB + QP;
+  return n * sizeof(double);
+}
+static int psi2_rowsP_qc(int M, int QP, int NT) {
+  static const bool off = getenv("RGP_PSI2_NO_SKEW") != nullptr;
+  if (off) return 0;
+  const size_t cap = 160 * 1024 - 64;                     // the kernel's static LDS (role tickets) comes on top
+  if (psi2_rowsP_lds(M, QP, NT, 4) <= cap) return 4;
+  if (psi2_rowsP_lds(M, QP, NT, 2) <= cap) return 2;
+  return 0;
 }
 
 // number of packed teams (0: use the four-team / two-team kernels)
@@ -1830,9 +2302,46 @@ static hipError_t psi2_dispatch(hipStream_t s, bool fwd, bool bwd, const Psi2Arg
     double* dbgbuf = nullptr;
 #ifdef PSI2_STAMPS                                   // per-stage cycle stamps (profiling builds: make CXXFLAGS+=-DPSI2_STAMPS, RGP_STAMPS=1)
     static double* dbgbuf_s = nullptr;
-    if (!dbgbuf_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf_s, 256 * 9 * sizeof(double));
+    if (!dbgbuf_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbgbuf_s, (2048 + 256 * 8 * 5 + 256 * 9) * sizeof(double));
     dbgbuf = dbgbuf_s;
 #endif
+    const int qc = psi2_rowsP_qc(a.M, QP, nt);
+    if (qc) {
+      const size_t lp = psi2_rowsP_lds(a.M, QP, nt, qc);
+      const int64_t per = ((a.N + nblk - 1) / nblk + nt - 1) / nt * nt;       // rows per workgroup, a multiple of the teams
+      const void* fn = (qc == 4) ? (const void*)psi2_rowsP_kernel<QP, 4> : (const void*)psi2_rowsP_kernel<QP, 2>;
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+      if (e != hipSuccess) return e;
+      if (qc == 4)
+        hipLaunchKernelGGL((psi2_rowsP_kernel<QP, 4>), dim3(nblk), dim3(PSI2_T4), lp, s, a.N, per, a.M, a.Q, nt, psi2_team_stride(a.M), a.Zc,
+                           a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu,
+                           a.o.gS, a.o.accumulate, dbgbuf);
+      else
+        hipLaunchKernelGGL((psi2_rowsP_kernel<QP, 2>), dim3(nblk), dim3(PSI2_T4), lp, s, a.N, per, a.M, a.Q, nt, psi2_team_stride(a.M), a.Zc,
+                           a.lam, a.dLs, a.Xmu, a.d2, a.g0, a.o.p2_part, a.o.dz_part, a.o.dlam_part, a.o.wsum_part, a.o.gmu,
+                           a.o.gS, a.o.accumulate, dbgbuf);
+#ifdef PSI2_STAMPS
+      if (dbgbuf) {
+        (void)hipStreamSynchronize(s);
+        static double hb[2048 + 256 * 8 * 5];
+        (void)hipMemcpy(hb, dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
+        double acc[2][4] = {{0}}; int cnt[2] = {0, 0}; double iters = 0;
+        for (int b = 0; b < nblk; ++b) for (int w = 0; w < 8; ++w) {
+          const int r = (int)hb[b * 8 + w] % 10;
+          const double* o = hb + 2048 + (b * 8 + w) * 4;
+          for (int i = 0; i < 3; ++i) acc[r][i] += o[i] / (o[3] > 0 ? o[3] : 1);
+          acc[r][3] += hb[2048 + 256 * 8 * 4 + b * 8 + w] / (o[3] > 0 ? o[3] : 1);
+          ++cnt[r]; iters = o[3];
+        }
+        fprintf(stderr, "psi2P QP=%d iters=%.0f wave0..7 simd/role:", QP, iters);
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " %02d", (int)hb[w]);
+        for (int r = 0; r < 2; ++r)
+          fprintf(stderr, " | role %d (%d waves) cycles/iter: sweep %.0f (first half of the pairs %.0f) pass %.0f barrier %.0f", r, cnt[r], acc[r][0] / cnt[r], acc[r][3] / cnt[r], acc[r][1] / cnt[r], acc[r][2] / cnt[r]);
+        fprintf(stderr, "\n");
+      }
+#endif
+      return hipSuccess;
+    }
     hipError_t e = hipFuncSetAttribute((const void*)psi2_rowsN_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((psi2_rowsN_kernel<QP>), dim3(nblk), dim3(PSI2_T4), ln, s, a.N, a.M, a.Q, nt, psi2_team_stride(a.M), a.Zc, a.lam, a.dLs, a.Xmu,
