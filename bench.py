@@ -179,9 +179,9 @@ def main():
         nl = len(m.layers)
         if a.config == 4:
             metric = 'SVI steps/sec, 2-layer RGP M=100 T=4096 (ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
-            kernel = 'psi2_rowsN_kernel (fused psi2 forward+backward, packed teams, fp64 VALU, 3 launches per step: Q=40,40,20)'
-            traffic = measured_traffic_bytes('r1_psi2_rowsN_traffic_raw.json')
-            tnote = 'bytes per Q=40 launch from a separate rocprofv3 --pmc pass (profiles/r1_psi2_rowsN_traffic_raw.json); algorithmic ~0.25e9'
+            kernel = 'psi2_rowsP_kernel (fused psi2 forward+backward, packed teams, the two waves of a SIMD half a step apart, fp64 VALU, 3 launches per step: Q=40,40,20)'
+            traffic = measured_traffic_bytes('r2_psi2_rowsP_traffic_raw.json')
+            tnote = 'bytes per Q=40 launch from separate rocprofv3 --pmc passes (profiles/r2_psi2_rowsP_traffic_raw.json); algorithmic ~0.27e9'
         else:
             metric = 'SVI steps/sec, 3-layer RGP M=500 T=65536 D=64 (BASELINE config 5; ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
             kernel = ('big_psi2_bwd_kernel (psi2 backward sweep over inducing blocks, fp64 VALU, 4 launches per step: Q=40,40,40,20); the '

@@ -28,7 +28,14 @@
 #define BF_RT 16
 #endif
 #ifndef BIG_BWD_SYNC_EVERY
-#define BIG_BWD_SYNC_EVERY 0      // power of two (inducing columns between two meetings of the workgroup's waves), 0 = never
+#define BIG_BWD_SYNC_EVERY 0      // power of two (inducing columns between two meetings of the workgroup's waves), 0 = never;
+                                  // M = 500, Q = 40: 35.0 TF never, 37.8 every 16, 38.6 every 64 (without the priority turns)
+#endif
+#ifndef BIG_BWD_PRIO_ALT
+#define BIG_BWD_PRIO_ALT 16       // columns per turn of the alternating issue priority of a SIMD's two waves (0: off).  The
+                                  // hardware serves the older wave first and the younger one in its gaps, so the two drift
+                                  // apart by more z rows than the scalar cache holds; with turns they advance together:
+                                  // 40.1 / 39.7 / 40.3 TF with turns of 4 / 8 / 16 columns
 #endif
 #ifndef BF_NP
 #define BF_NP 2           // inducing columns per lane for padded Q <= 48 (1: half the registers, four waves per SIMD)
@@ -502,6 +509,12 @@ big_psi2_bwd_kernel(const int64_t N, const int M, const int IB, const int TS, co
         // rows than the 16 KB scalar cache holds (Z is 160 KB at M = 500) and each wave fetches its rows from L2 again;
         // meeting every few rows keeps them within one cache-full of each other.
         if ((mp & (BIG_BWD_SYNC_EVERY - 1)) == 0) __syncthreads();
+#endif
+#if BIG_BWD_PRIO_ALT > 0
+        // the two waves of a SIMD (w and w + 4) take the higher issue priority in turns of BIG_BWD_PRIO_ALT columns
+        if ((mp & (BIG_BWD_PRIO_ALT - 1)) == 0) {
+          if ((((mp / BIG_BWD_PRIO_ALT) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
 #endif
         double dlc[4];
 #pragma unroll
