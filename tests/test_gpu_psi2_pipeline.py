@@ -1,0 +1,32 @@
+"""The fused psi2 pass over MANY iterations per workgroup, against the oracle.
+
+The packed-team psi2 kernels walk their rows in iterations of NT rows per workgroup and publish row operands, h values and
+partial row sums through rings of five, two and three slots; the short sequences of the other model tests give every
+workgroup a single iteration.  Here one long sequence makes every workgroup run six or more (232 workgroups x NT rows x 6),
+with a ragged last iteration, and the ELBO and every gradient are compared with the oracle as in test_gpu_model
+(1e-11 on the bound, 1e-9 of the largest entry on each gradient group)."""
+import pytest
+
+from test_gpu_model import build_pair, compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('cfg', [
+    # config-4 geometry (M = 100: five rows in flight, the reduction scratch of the two-role kernel in its narrow form)
+    dict(wins=(0, 20, 20), nDims=(16, 1, 1), n_seq=1, T=7303, M=100, U_win=20, u_dim=1, y_dim=16),
+    # small M (eight rows in flight, one partly idle wave per team), three hidden layers with different windows
+    dict(wins=(0, 5, 4, 3), nDims=(2, 1, 2, 1), n_seq=1, T=12011, M=6, y_dim=2),
+    # M = 50: teams of 64 lanes, Q = 20 + 20 (the wide form of the reduction scratch)
+    dict(wins=(0, 20, 20), nDims=(1, 1, 1), n_seq=2, T=6007, M=50, U_win=20, u_dim=1, y_dim=1),
+])
+def test_many_iterations_per_workgroup_match_oracle(cfg):
+    o, g = build_pair(fast_psi=True, chunk=512, **cfg)
+    compare(o, g)
+
+
+def test_minibatch_of_long_sequences_matches_oracle():
+    """Two of three long ragged sequences (qU_ratio = 2/3): the table slice and the rings together."""
+    o, g = build_pair(wins=(0, 6, 6), nDims=(3, 2, 2), n_seq=3, T=4001, M=12, U_win=6, ragged=True, n_total=3, fast_psi=True,
+                      chunk=512)
+    compare(o, g, seqs=[0, 2])
