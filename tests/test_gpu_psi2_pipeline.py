@@ -19,6 +19,9 @@ pytestmark = pytest.mark.gpu
     dict(wins=(0, 5, 4, 3), nDims=(2, 1, 2, 1), n_seq=1, T=12011, M=6, y_dim=2),
     # M = 50: teams of 64 lanes, Q = 20 + 20 (the wide form of the reduction scratch)
     dict(wins=(0, 20, 20), nDims=(1, 1, 1), n_seq=2, T=6007, M=50, U_win=20, u_dim=1, y_dim=1),
+    # the widest windows: Q = 60 (padded to 64: a z row no longer fits the scalar registers at once) and Q = 45 (padded to 48)
+    dict(wins=(0, 30, 30), nDims=(2, 1, 1), n_seq=1, T=12040, M=20, U_win=30, u_dim=1, y_dim=2),
+    dict(wins=(0, 15, 15), nDims=(2, 2, 1), n_seq=1, T=12017, M=33, U_win=15, u_dim=1, y_dim=2),
 ])
 def test_many_iterations_per_workgroup_match_oracle(cfg):
     o, g = build_pair(fast_psi=True, chunk=512, **cfg)
