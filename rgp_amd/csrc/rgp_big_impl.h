@@ -299,6 +299,27 @@ big_psi2_fwd_kernel(const int64_t N, const int M, const int ntasks, const double
   const int m = 64 * ib + lane;
   const bool act = has_task && m < M;
   const int mc = m < M ? m : M - 1;
+  // The lane's own z row is needed again for every column group of every row tile (the products zz are rebuilt per group).
+  // As global loads that is 20 loads of 64 different cache lines each per group, and the wave waits for them; the rows of the
+  // workgroup's inducing blocks (at most three: eight consecutive tasks) are therefore kept transposed in LDS, [q][lane].
+  constexpr bool STRIP = QP <= 48;
+  double* zstrip = lds + PSI2_EXP_TAB + (size_t)8 * BF_RT * (64 + CG4);       // [3][QP][64]   (STRIP)
+  const double* zl = zstrip;
+  if (STRIP) {
+    int ib0 = 0, task0 = (int)blockIdx.x * 8;
+    for (; ib0 < nIB - 1; ++ib0) {
+      const int cnt = nSG - (64 * ib0) / CG;
+      if (task0 < cnt) break;
+      task0 -= cnt;
+    }
+    const int sidx = has_task ? ib - ib0 : 0;                    // 0..2
+    double* zw = zstrip + (size_t)sidx * QP * 64 + lane;
+    if (has_task) {
+#pragma unroll
+      for (int q = 0; q < QP; ++q) zw[q * 64] = Zc[(size_t)mc * QP + q];       // waves of one block write the same values
+    }
+    zl = zw;
+  }
   const int64_t per = (N + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = (int64_t)blockIdx.y * per;
   const int64_t r1 = (r0 + per < N) ? r0 + per : N;
@@ -350,7 +371,7 @@ big_psi2_fwd_kernel(const int64_t N, const int M, const int ntasks, const double
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int q = 0; q < QP; ++q) zz[p][q] = Zc[(size_t)mc * QP + q] * Zc[(size_t)mp[p] * QP + q];
+        for (int q = 0; q < QP; ++q) zz[p][q] = (STRIP ? zl[q * 64] : Zc[(size_t)mc * QP + q]) * Zc[(size_t)mp[p] * QP + q];
       }
       const int nr = (int)(re - rt);
       for (int r = 0; r < nr; ++r) {
@@ -394,7 +415,7 @@ __global__ void __launch_bounds__(256) big_psi2_unpack_kernel(int M, int nchunk,
 static rgp_status launch_big_psi2_fwd(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, const ZTerms& zt,
                                       const RowTerms& rt, const double* dm, const double* H, double* part, double* psi2) {
   const dim3 grid((unsigned)((p.fwd_tasks + 7) / 8), (unsigned)p.fwd_chunks);
-  const size_t lds = (PSI2_EXP_TAB + (size_t)8 * BF_RT * (64 + 16)) * sizeof(double);
+  const size_t lds = (PSI2_EXP_TAB + (size_t)8 * BF_RT * (64 + 16) + (zt.QP <= 48 ? (size_t)3 * zt.QP * 64 : 0)) * sizeof(double);
   switch (zt.QP) {
 #define B2F(qp, np)                                                                                                        \
   case qp: {                                                                                                               \
