@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 measurements of config 4 at the current state (run on the GPU box from the repo root)
+# measurements of config 4: GPU tests, bench line, kernel statistics, HBM traffic of the psi2 kernel (run on the GPU box from the repo root)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/m4

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 measurements of config 5 at full size (run on the GPU box from the repo root)
+# measurements of config 5 at full size: bench line and kernel statistics (run on the GPU box from the repo root)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/m5
