@@ -82,7 +82,35 @@ static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
   return p;
 }
 
+#define WQ_QC 128             // wide windows (rgp_wideq_impl.h): window columns per chunk of the psi2 products
+#define WQ_MAX_QP 1024        // widest padded window
+struct WqWs {                 // what the wide-window psi2 term needs beyond the blocked path's buffers
+  double *E, *A, *vrow, *T, *DM, *S22, *p2w_part, *dz3_part, *dz3, *B_part, *B1, *B2;
+  int nexp, nsplit;
+};
+
+static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q, int num_cu) {
+  const size_t NM = (size_t)N * M;
+  Q.nexp = (int)((N + 63) / 64 < 4 * num_cu ? (N + 63) / 64 : 4 * num_cu);
+  if (Q.nexp < 1) Q.nexp = 1;
+  Q.nsplit = p.sk;
+  Q.E = ws.take<double>(NM * M);
+  Q.A = ws.take<double>(NM * WQ_QC);
+  Q.vrow = ws.take<double>(NM);
+  Q.T = ws.take<double>((size_t)N * p.QP);
+  Q.DM = ws.take<double>((size_t)N * p.QP);
+  Q.S22 = ws.take<double>((size_t)N * p.W);
+  Q.p2w_part = ws.take<double>((size_t)Q.nexp * M * M);
+  Q.dz3_part = ws.take<double>((size_t)Q.nsplit * M * p.QP);
+  Q.dz3 = ws.take<double>((size_t)M * p.QP);
+  Q.B_part = ws.take<double>((size_t)p.sk * M * p.QP);
+  Q.B1 = ws.take<double>((size_t)M * p.QP);
+  Q.B2 = ws.take<double>((size_t)M * p.QP);
+  return ws.off;
+}
+
 struct BigWs {
+  WqWs wq; bool wide;
   ZTerms zt; RowTerms rt;
   double *dm, *P, *Lp, *H, *gmu, *gS, *Ym, *Yv, *dYm, *S12, *ZZ;
   double *p2_part, *psi2, *dLs;
@@ -125,6 +153,8 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
   L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
+  L.wide = QP > RGP_MAX_QP;
+  if (L.wide) wq_carve(ws, p, N, M, L.wq, 256);
   return ws.off;
 }
 
@@ -137,6 +167,8 @@ static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D) {
 }
 
 static inline unsigned big_nb256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+#include "rgp_wideq_impl.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // small element-wise kernels
@@ -233,7 +265,7 @@ __global__ void __launch_bounds__(256) big_rows1_kernel(int64_t N, int Q, int QP
                                                          double* __restrict__ lsum_part) {
   __shared__ double sm[4][64];
   __shared__ double sl[4];
-  const int q = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int q = (int)blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;     // blockIdx.y: 64 window columns each
   double dl = 0.0, ls = 0.0;
   const double il = (q < Q) ? 1.0 / lam[q] : 0.0;
   for (int64_t n = (int64_t)blockIdx.x * 4 + g; n < N; n += (int64_t)gridDim.x * 4) {
@@ -252,11 +284,12 @@ __global__ void __launch_bounds__(256) big_rows1_kernel(int64_t N, int Q, int QP
       gS[n * QP + q] = 0.0;
     }
   }
-  sm[g][q] = dl;
+  const int ql = threadIdx.x & 63;
+  sm[g][ql] = dl;
   if (q == 0) sl[g] = ls;
   __syncthreads();
   if (g == 0) {
-    if (q < QP) dlam_part[(size_t)blockIdx.x * QP + q] = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
+    if (q < QP) dlam_part[(size_t)blockIdx.x * QP + q] = (sm[0][ql] + sm[1][ql]) + (sm[2][ql] + sm[3][ql]);
     if (q == 0) lsum_part[blockIdx.x] = (sl[0] + sl[1]) + (sl[2] + sl[3]);
   }
 }
@@ -681,7 +714,7 @@ static void launch_big_psi1_bwd(hipStream_t s, const BigPlan& p, int64_t N, int 
     g.m = (int)N; g.n = p.W; g.k = M; g.A = L.Lp; g.lda = M; g.B = L.ZZ; g.ldb = p.W; g.C = L.S12; g.ldc = p.W;
     launch_gemm(s, g);
   }
-  hipLaunchKernelGGL(big_rows1_kernel, dim3(p.rows_blk), dim3(256), 0, s, N, Q, QP, p.W, L.S12, rt.Xmu, rt.e1, zt.lam, L.gmu, L.gS,
+  hipLaunchKernelGGL(big_rows1_kernel, dim3(p.rows_blk, (QP + 63) / 64), dim3(256), 0, s, N, Q, QP, p.W, L.S12, rt.Xmu, rt.e1, zt.lam, L.gmu, L.gS,
                      L.dlam1_part, L.lsum1_part);
   for (int k = 0; k < 2; ++k) {                              // A1 = Lp^T (e mu), A2 = Lp^T e   (sums over the data rows: split K)
     GemmArgs g;
@@ -696,10 +729,14 @@ static void launch_big_psi1_bwd(hipStream_t s, const BigPlan& p, int64_t N, int 
   launch_reduce_batch(s, 2, segs);
 }
 
-static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q) {
+static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok = false) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
   if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
-  if (rgp_qp(Q) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
+  if (rgp_qp(Q) > RGP_MAX_QP) {
+    if (!wide_ok) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is supported by the SVI layer step only");
+    if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 needs M <= 128");
+    if (rgp_qp(Q) > WQ_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 1024 is not supported by this build");
+  }
   if (N > 0x7fffffffLL / 2) return rgp_fail(h, RGP_ERR_BAD_ARG, "more than 2^30 data rows in one call");
   return RGP_OK;
 }
@@ -789,7 +826,7 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
-  rgp_status st = big_check(h, N, M, Q);
+  rgp_status st = big_check(h, N, M, Q, true);
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
   if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
@@ -826,9 +863,15 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
   c.gqU_m = out->gqU_m; c.gqU_W = out->gqU_W; c.gqU_a = out->gqU_a; c.winv = out->woodbury_inv;
   if ((st = launch_svi_chain_pre(h, c, s))) return st;
+  if (M <= RGP_MAX_M)       // the single-workgroup chain (M <= 128) does not leave the device scalars the products below use
+    hipLaunchKernelGGL(wq_scal_kernel, dim3(1), dim3(64), 0, s, in->noise, D, c.scal);
 
   // psi1 side
-  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
+  if (L.wide)
+    hipLaunchKernelGGL(wq_psi1_fwd_kernel, dim3((unsigned)(N < 8192 ? N : 8192)), dim3(128), 0, s, N, M, QP, L.zt.ZcT, L.zt.lam,
+                       L.rt.e1, L.rt.em, L.rt.d2, L.rt.Xmu, L.rt.g1, L.P, L.H);
+  else
+    launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
   {                                                          // Lp = psi1 o (Ym Cpsi1^T)              (svi_vardtc.py:164-167)
     GemmArgs g;
     g.m = (int)N; g.n = M; g.k = D; g.A = L.Ym; g.lda = D; g.B = c.Cpsi1; g.ldb = D; g.tb = 1; g.C = L.Lp; g.ldc = M;
@@ -851,8 +894,12 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
 
   // psi2: forward sum, then backward with the symmetrised dL/dpsi2 of the chain
-  st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
-  if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1, true);
+  if (L.wide) {
+    st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
+  } else {
+    st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
+    if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1, true);
+  }
   if (st) return st;
 
   // latent gradients

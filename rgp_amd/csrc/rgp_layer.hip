@@ -477,14 +477,14 @@ struct FinalizeArgs {
   double *gZ, *ginv_l, *gvariance;   // [M x Q], [Q], [1]
 };
 
-// grid = M workgroups (one inducing row each) of 64 x 4 threads: lane q, 4 slices of m'.
+// grid = M workgroups (one inducing row each; blockIdx.y: 64 window columns each) of 64 x 4 threads: lane q, 4 slices of m'.
 // Writes gZ[m,:], the per-row dinv_l contributions dlrow[m,:] and the per-row sum of dKmm*K.
 __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, double* __restrict__ dlrow,
                                                              double* __restrict__ gsum_row) {
   __shared__ double sm[2][4][64];
   __shared__ double scratch[16];
   const int M = a.M, Q = a.Q, QP = a.QP;
-  const int m = blockIdx.x, q = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int m = blockIdx.x, ql = threadIdx.x & 63, q = (int)blockIdx.y * 64 + ql, sl = threadIdx.x >> 6;
   double s1 = 0.0, s2 = 0.0, gs = 0.0;
   const double zm = (q < QP) ? a.Zc[m * QP + q] : 0.0;
   for (int mp = sl; mp < M; mp += 4) {
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, doub
       const double k1 = a.Kj[m * M + mp] - (m == mp ? RGP_JITTER : 0.0);
       gk = a.dk_scale * a.dKmm[m * M + mp] * k1;
       gkT = a.dk_scale * a.dKmm[mp * M + m] * k1;
-      if (q == 0) gs += gk;
+      if (ql == 0) gs += gk;
     }
     if (a.dLs) ws = a.dLs[m * M + mp] * a.psi2[m * M + mp];
     if (q < QP) {
@@ -502,13 +502,13 @@ __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, doub
       s2 += (gk + 0.5 * ws) * df * df;
     }
   }
-  sm[0][sl][q] = s1;
-  sm[1][sl][q] = s2;
+  sm[0][sl][ql] = s1;
+  sm[1][sl][ql] = s2;
   const double gtot = block_sum(gs, scratch);
   __syncthreads();
   if (sl == 0 && q < QP) {
-    s1 = (sm[0][0][q] + sm[0][1][q]) + (sm[0][2][q] + sm[0][3][q]);
-    s2 = (sm[1][0][q] + sm[1][1][q]) + (sm[1][2][q] + sm[1][3][q]);
+    s1 = (sm[0][0][ql] + sm[0][1][ql]) + (sm[0][2][ql] + sm[0][3][ql]);
+    s2 = (sm[1][0][ql] + sm[1][1][ql]) + (sm[1][2][ql] + sm[1][3][ql]);
     if (q < Q) {
       double dz = -a.lam[q] * s1;
       if (a.dz1) dz += a.dz1[m * QP + q];
@@ -517,19 +517,19 @@ __global__ void __launch_bounds__(256) finalize_rows_kernel(FinalizeArgs a, doub
     }
     dlrow[m * QP + q] = (q < Q) ? -0.5 * s2 : 0.0;
   }
-  if (threadIdx.x == 0) gsum_row[m] = gtot;
+  if (threadIdx.x == 0 && blockIdx.y == 0) gsum_row[m] = gtot;
 }
 
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a, const double* __restrict__ dlrow,
                                                         const double* __restrict__ gsum_row) {
   const int M = a.M, Q = a.Q, QP = a.QP, t = threadIdx.x;
   const double var = a.variance[0];
-  if (t < Q) {
+  for (int q = t; q < Q; q += 256) {
     double s = 0.0;
-    for (int m = 0; m < M; ++m) s += dlrow[m * QP + t];
-    if (a.dlam1) s += a.dlam1[t];
-    if (a.dlam2) s += a.dlam2[t];
-    a.ginv_l[t] = s;
+    for (int m = 0; m < M; ++m) s += dlrow[m * QP + q];
+    if (a.dlam1) s += a.dlam1[q];
+    if (a.dlam2) s += a.dlam2[q];
+    a.ginv_l[q] = s;
   }
   if (t == 0) {
     double gsum = 0.0;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a, const dou
 }
 
 static void launch_finalize(hipStream_t s, const FinalizeArgs& f, double* dlrow, double* gsum_row) {
-  hipLaunchKernelGGL(finalize_rows_kernel, dim3(f.M), dim3(256), 0, s, f, dlrow, gsum_row);
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(f.M, (f.QP + 63) / 64), dim3(256), 0, s, f, dlrow, gsum_row);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, f, dlrow, gsum_row);
 }
 
@@ -764,7 +764,7 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
 
 static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D);
 extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
-  if (M > RGP_MAX_M) return big_workspace_bytes(N, M, Q, D);
+  if (M > RGP_MAX_M || rgp_qp(Q) > RGP_MAX_QP) return big_workspace_bytes(N, M, Q, D);
   rgp_ctx tmp;
   LayerWs L;
   SviChain ch{}; ch.M = M; ch.D = D > 0 ? D : 1;
@@ -772,6 +772,8 @@ extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
 }
 
 static inline bool rgp_is_big(int M) { return M > RGP_MAX_M; }
+// windows wider than 64 columns (SVI layer step only): the GEMM-shaped path of rgp_wideq_impl.h
+static inline bool rgp_is_wide(const rgp_layer_in* in) { return rgp_qp(in->X_win * in->X_dim + in->U_win * in->U_dim) > RGP_MAX_QP; }
 
 static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
@@ -1253,7 +1255,7 @@ extern "C" rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, co
 extern "C" rgp_status rgp_layer_prepare(rgp_handle h, const rgp_layer_in* in) {
   if (!h || !in) return RGP_ERR_BAD_ARG;
   if (in->mode != RGP_MODE_SVI) return RGP_OK;
-  if (rgp_is_big(in->M)) return RGP_OK;            // the blocked path runs whole layer steps on the main stream
+  if (rgp_is_big(in->M) || rgp_is_wide(in)) return RGP_OK;      // the blocked path runs whole layer steps on the main stream
   rgp_status st = svi_check_args(h, in);
   if (st) return st;
   const int flags = in->reserved & (RGP_PREPARE_CHAIN_ONLY | RGP_PREPARE_ROWS_ONLY);
@@ -1318,7 +1320,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (!h || !in || !out) return RGP_ERR_BAD_ARG;
   if (in->mode == RGP_MODE_VARDTC) return vardtc_layer_step(h, in, out);
   if (in->mode != RGP_MODE_SVI) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_layer_step: unknown mode");
-  if (rgp_is_big(in->M)) return big_svi_layer_step(h, in, out);
+  if (rgp_is_big(in->M) || rgp_is_wide(in)) return big_svi_layer_step(h, in, out);
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
