@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', type=int, default=4, choices=[4, 5], help='BASELINE.json config (4: the metric; 5: M=500, T=65536)')
+    ap.add_argument('--wide', action='store_true',
+                    help='config 4 read with 16-dimensional hidden layers: lag windows of 340 / 640 / 320 columns (GEMM-shaped psi2)')
     ap.add_argument('--lr', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-update', action='store_true', help='debug: skip the Adam update (kernel ablation runs); INVALID as a benchmark')
@@ -68,7 +70,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from rgp_amd.synthetic import CONFIG4, CONFIG5, generate_sequences
+    from rgp_amd.synthetic import CONFIG4, CONFIG4W, CONFIG5, generate_sequences
     from rgp_amd.model import DeepAutoreg
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -93,12 +95,13 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    cfg = dict(CONFIG4 if a.config == 4 else CONFIG5)
+    assert not (a.wide and a.config != 4)
+    cfg = dict((CONFIG4W if a.wide else CONFIG4) if a.config == 4 else CONFIG5)
     n_total = a.n_total or cfg['n_total']
     T = a.T or cfg['T']
     mb = a.minibatch or cfg['minibatch']
-    steps = a.steps if a.steps is not None else (20 if a.config == 4 else 3)
-    warmup = a.warmup if a.warmup is not None else (3 if a.config == 4 else 1)
+    steps = a.steps if a.steps is not None else (20 if (a.config == 4 and not a.wide) else 3)
+    warmup = a.warmup if a.warmup is not None else (3 if (a.config == 4 and not a.wide) else 1)
     assert n_total % world == 0 and mb % world == 0
     n_loc, mb_loc = n_total // world, mb // world
 
@@ -177,7 +180,15 @@ def main():
         flops = 4.0 * psi2_nmmq                      # 4 Q flop per (n, m, m')
         achieved = flops / (psi2_ms * 1e-3) / 1e12 if psi2_ms > 0 else 0.0
         nl = len(m.layers)
-        if a.config == 4:
+        if a.wide:
+            metric = ('SVI steps/sec, 2-layer RGP M=100 T=4096 with 16-dimensional hidden layers (windows of 340/640/320 columns; '
+                      'ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)')
+            kernel = ('gemm_f64_kernel (v_mfma_f64_16x16x4) inside the GEMM-shaped psi2 term: per 128-column chunk of the window one '
+                      'batched Gram product and one batched back product over the N x M x M weights in HBM; the time is that of the '
+                      'whole psi2 term of a layer (products + exp pass + reductions), 3 per step')
+            traffic = None
+            tnote = 'not collected for this workload'
+        elif a.config == 4:
             metric = 'SVI steps/sec, 2-layer RGP M=100 T=4096 (ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
             kernel = 'psi2_rowsP_kernel (fused psi2 forward+backward, packed teams, the two waves of a SIMD half a step apart, fp64 VALU, 3 launches per step: Q=40,40,20)'
             traffic = measured_traffic_bytes('r2_psi2_rowsP_traffic_raw.json')
@@ -259,7 +270,7 @@ def cpu_baseline(cfg, Us, Ys, m, mb, n_total, T):
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-    big = cfg['M'] > 128
+    big = cfg['M'] > 128 or max(cfg['nDims'][1:]) > 4        # the oracle's psi2 work per row grows with M * M * Q: a shorter sample
     T_s = min(len(Ys[0]), 4096 if not big else 276)
     rows_per_seq_full = len(Ys[0]) - cfg['U_win']
     rows_s = T_s - cfg['U_win']

@@ -168,6 +168,11 @@ static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D) {
 
 static inline unsigned big_nb256(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+__global__ void __launch_bounds__(256) big_fill_kernel(int64_t n, double* __restrict__ x, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
 #include "rgp_wideq_impl.h"
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -769,10 +774,6 @@ __global__ void __launch_bounds__(256) big_mul_kernel(int64_t n, const double* _
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] * b[i];
 }
-__global__ void __launch_bounds__(256) big_fill_kernel(int64_t n, double* __restrict__ x, double v) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = v;
-}
 
 static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
                                    const double* variance, const double* inv_l, double dL_dpsi0_sum, const double* dL_dpsi1,
@@ -895,7 +896,9 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // psi2: forward sum, then backward with the symmetrised dL/dpsi2 of the chain
   if (L.wide) {
+    prof_begin(h, (double)N * M * M * Q);                     // rgp_get_profile times the whole GEMM-shaped psi2 term
     st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
+    prof_end(h);
   } else {
     st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
     if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1, true);

@@ -198,7 +198,7 @@ static rgp_status wq_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t
     launch_gemm(s, g);
   }
   // exponential pass: W in place of E, forward partial sums, v
-  RGP_HIP_CHECK(h, hipMemsetAsync(X.vrow, 0, (size_t)NM * sizeof(double), s));
+  hipLaunchKernelGGL(big_fill_kernel, dim3(big_nb256(NM)), dim3(256), 0, s, NM, X.vrow, 0.0);
   hipLaunchKernelGGL(wq_exp_kernel, dim3(X.nexp), dim3(256), 0, s, N, M, X.E, L.rt.g0, L.H, L.dLs, X.p2w_part, X.vrow);
   launch_reduce(s, X.nexp, (int64_t)M * M, (int64_t)M * M, X.p2w_part, L.psi2, 1.0, 0);
   // back: per chunk Y = W Z_c, then the two reductions of Y

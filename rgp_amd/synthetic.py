@@ -7,6 +7,12 @@ CONFIG4 = dict(name='config4: synthetic T=4096 D_y=16 D_u=1, 2 hidden layers H=[
                n_total=256, T=4096, D_y=16, D_u=1, wins=[0, 20, 20], nDims=[16, 1, 1], U_win=20, M=100, minibatch=32)
 
 
+# the other reading of "D=16": the hidden layers are 16-dimensional too, so the lag windows are 340 / 640 / 320 columns wide
+CONFIG4W = dict(name='config4-wide: synthetic T=4096 D_y=16 D_u=1, 2 hidden layers H=[16,16], wins=[0,20,20], U_win=20, M=100 '
+                     '(windows of 340 / 640 / 320 columns), SVI minibatch 32 of 256 sequences',
+                n_total=256, T=4096, D_y=16, D_u=1, wins=[0, 20, 20], nDims=[16, 16, 16], U_win=20, M=100, minibatch=32)
+
+
 CONFIG5 = dict(name='config5: synthetic T=65536 D_y=64 D_u=1, 3 hidden layers H=[1,1,1], wins=[0,20,20,20], U_win=20, M=500, '
                     'SVI minibatch 8 of 16 sequences',
                n_total=16, T=65536, D_y=64, D_u=1, wins=[0, 20, 20, 20], nDims=[64, 1, 1, 1], U_win=20, M=500, minibatch=8)
