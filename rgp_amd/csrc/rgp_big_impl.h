@@ -82,30 +82,38 @@ static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
   return p;
 }
 
-#define WQ_QC 128             // wide windows (rgp_wideq_impl.h): window columns per chunk of the psi2 products
-#define WQ_MAX_QP 1024        // widest padded window
+#define WQ_MAX_QP 1024        // widest padded window of the wide path (rgp_wideq_impl.h)
+#define WQ_RB 24              // data rows per workgroup of its exponential pass (two M-wide LDS rows each: 48 KB at M = 128)
 struct WqWs {                 // what the wide-window psi2 term needs beyond the blocked path's buffers
-  double *E, *A, *vrow, *T, *DM, *S22, *p2w_part, *dz3_part, *dz3, *B_part, *B1, *B2;
-  int nexp, nsplit;
+  double *E, *ZZ2, *vrow, *T, *DM, *S22, *p2w_part, *p2pair, *C_part, *dz3, *B_part, *B1, *B2, *ellq;
+  int *pa, *pb;
+  int P, nexp, nsplit;
 };
 
-static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q, int num_cu) {
-  const size_t NM = (size_t)N * M;
-  Q.nexp = (int)((N + 63) / 64 < 4 * num_cu ? (N + 63) / 64 : 4 * num_cu);
+static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q) {
+  const int P = M * (M + 1) / 2;
+  Q.P = P;
+  Q.nexp = (int)((N + WQ_RB - 1) / WQ_RB);
   if (Q.nexp < 1) Q.nexp = 1;
-  Q.nsplit = p.sk;
-  Q.E = ws.take<double>(NM * M);
-  Q.A = ws.take<double>(NM * WQ_QC);
-  Q.vrow = ws.take<double>(NM);
+  const int tiles = ((P + 63) / 64) * ((p.QP + 63) / 64);
+  Q.nsplit = (2048 + tiles - 1) / tiles;
+  if (Q.nsplit > 16) Q.nsplit = 16;
+  Q.E = ws.take<double>((size_t)N * P);
+  Q.ZZ2 = ws.take<double>((size_t)p.QP * P);
+  Q.vrow = ws.take<double>((size_t)N * M);
   Q.T = ws.take<double>((size_t)N * p.QP);
   Q.DM = ws.take<double>((size_t)N * p.QP);
   Q.S22 = ws.take<double>((size_t)N * p.W);
-  Q.p2w_part = ws.take<double>((size_t)Q.nexp * M * M);
-  Q.dz3_part = ws.take<double>((size_t)Q.nsplit * M * p.QP);
+  Q.p2w_part = ws.take<double>((size_t)Q.nexp * P);
+  Q.p2pair = ws.take<double>(P);
+  Q.C_part = ws.take<double>((size_t)Q.nsplit * P * p.QP);
   Q.dz3 = ws.take<double>((size_t)M * p.QP);
   Q.B_part = ws.take<double>((size_t)p.sk * M * p.QP);
   Q.B1 = ws.take<double>((size_t)M * p.QP);
   Q.B2 = ws.take<double>((size_t)M * p.QP);
+  Q.ellq = ws.take<double>(M);
+  Q.pa = ws.take<int>(P);
+  Q.pb = ws.take<int>(P);
   return ws.off;
 }
 
@@ -154,7 +162,7 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
   L.wide = QP > RGP_MAX_QP;
-  if (L.wide) wq_carve(ws, p, N, M, L.wq, 256);
+  if (L.wide) wq_carve(ws, p, N, M, L.wq);
   return ws.off;
 }
 
@@ -869,8 +877,7 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
 
   // psi1 side
   if (L.wide)
-    hipLaunchKernelGGL(wq_psi1_fwd_kernel, dim3((unsigned)(N < 8192 ? N : 8192)), dim3(128), 0, s, N, M, QP, L.zt.ZcT, L.zt.lam,
-                       L.rt.e1, L.rt.em, L.rt.d2, L.rt.Xmu, L.rt.g1, L.P, L.H);
+    wq_psi1_fwd(s, p, N, M, L, L.wq);
   else
     launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
   {                                                          // Lp = psi1 o (Ym Cpsi1^T)              (svi_vardtc.py:164-167)

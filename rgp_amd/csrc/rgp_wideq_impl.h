@@ -3,10 +3,12 @@
 //
 // With Q in the hundreds the per-thread arrays of the sweep kernels (dzl[Q], y[Q]) cannot stay in registers, and the two
 // O(N M^2 Q) contractions of the psi2 term become what they are algebraically: batched matrix products with the data rows as
-// the batch, run on the MFMA GEMM (rgp_gemm.hip) in chunks of WQ_QC window columns, with the N x M x M weights in HBM:
-//   gram   E[(n,m), m'] (+)= A_c Z_c^T,      A_c[(n,m), q] = dm[n,q] z[m,q]           (A_c written by wq_a_kernel)
-//   exp    W = dLs o exp(E + g0[n] + H[n,m] + H[n,m']);  psi2 += sum_n exp(.);  v[n,m] = sum_m' W      (wq_exp_kernel, W in place)
-//   back   Y_c[(n,m), q] = W Z_c;   T[n,q] = sum_m z[m,q] Y_c;   dZ3[m,q] = sum_n d2[n,q] Y_c          (wq_t_kernel, wq_dz3_kernel)
+// the batch.  Written over the P = M (M + 1) / 2 pairs of inducing rows (the weights are symmetric) they are three plain, large
+// matrix products on the MFMA GEMM (rgp_gemm.hip), with the N x P weights in HBM:
+//   gram   E[n, p] = sum_q dm[n,q] ZZ2[q,p],   ZZ2[q,p] = z[a,q] z[b,q] for the pair p = (a <= b)            (N x P x Q product)
+//   exp    W = dLs o exp(E + g0[n] + h[n,a] + h[n,b]);  psi2 = sum_n exp(.);  v[n,m] = sum_m' W           (wq_exp_kernel, c o W in place)
+//   back   T[n,q] = sum_p c_p W[n,p] ZZ2[q,p]   (N x Q x P product);   C[p,q] = sum_n c_p W[n,p] d2[n,q]   (P x Q x N product),
+//          dZ3[m,q] = sum_m' z[m',q] C[(m,m'),q] / c
 // and, once per layer step, from v alone:  [a1 | vz2 | w] = V [Z | Z^2 | 1],  B1 = V^T (d2 o mu),  B2 = V^T d2, so that
 //   a23 = (vz2 + T) / 2,  row gradients as in the sweep kernels' epilogue,  dZ2 = 2 B1 - Z o B2 - dZ3.
 // (psi2 exponent and its gradients: GPy's rbf_psi_comp closed forms as restated in rgp_psi.hip; bound algebra:
@@ -23,118 +25,154 @@ __global__ void wq_scal_kernel(const double* __restrict__ noise, int D, double* 
   }
 }
 
-// P[n,m] = exp(g1[n] - 1/2 sum_q z (e z - 2 e mu));   H[n,m] = sum_q d2 z (mu - z/4) - 1/4 sum_q lam z^2      (any Q, M <= 128)
-// thread = inducing row m (z read from the transposed copy: coalesced), the row's operands are wave-uniform loads
-__global__ void __launch_bounds__(128) wq_psi1_fwd_kernel(const int64_t N, const int M, const int QP, const double* __restrict__ ZcT,
-                                                           const double* __restrict__ lam, const double* __restrict__ e1,
-                                                           const double* __restrict__ em, const double* __restrict__ d2,
-                                                           const double* __restrict__ Xmu, const double* __restrict__ g1,
-                                                           double* __restrict__ P, double* __restrict__ H) {
-  const int m = threadIdx.x;
-  const bool act = m < M;
-  double ellq = 0.0;
-  for (int q = 0; q < QP; ++q) { const double z = ZcT[(size_t)q * RGP_PSI2_TEAM + m]; ellq += 0.25 * lam[q] * z * z; }
-  for (int64_t r = blockIdx.x; r < N; r += gridDim.x) {
-    const double* __restrict__ e = e1 + r * QP;
-    const double* __restrict__ mm = em + r * QP;
-    const double* __restrict__ d = d2 + r * QP;
-    const double* __restrict__ mu = Xmu + r * QP;
-    double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
-    for (int q = 0; q < QP; q += 2) {
-      const double z0 = ZcT[(size_t)q * RGP_PSI2_TEAM + m], z1 = ZcT[(size_t)(q + 1) * RGP_PSI2_TEAM + m];
-      a0 += z0 * (e[q] * z0 - 2.0 * mm[q]);
-      a1 += z1 * (e[q + 1] * z1 - 2.0 * mm[q + 1]);
-      h0 += z0 * d[q] * (mu[q] - 0.25 * z0);
-      h1 += z1 * d[q + 1] * (mu[q + 1] - 0.25 * z1);
-    }
-    if (act) {
-      P[r * M + m] = exp(g1[r] - 0.5 * (a0 + a1));
-      H[r * M + m] = (h0 + h1) - ellq;
-    }
-  }
-}
-
-// A[(n,m), j] = dm[n, q0 + j] z[m, q0 + j]   (j < qc; zero beyond the padded width)
-__global__ void __launch_bounds__(256) wq_a_kernel(const int64_t NM, const int M, const int QP, const int q0, const int qc,
-                                                    const double* __restrict__ dm, const double* __restrict__ Zc,
-                                                    double* __restrict__ A) {
-  const int64_t total = NM * qc;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / qc;
-    const int j = (int)(i - row * qc);
-    const int64_t n = row / M;
-    const int m = (int)(row - n * M);
-    const int q = q0 + j;
-    A[i] = (q < QP) ? dm[n * QP + q] * Zc[(size_t)m * QP + q] : 0.0;
-  }
-}
-
-// The exponential pass over E[(n,m), m'] (row stride M).  Workgroup = block of data rows, team of 128 threads = one inducing
-// row m at a time (thread j = m'); for every m the team walks the block's rows n:
-//   p = exp(E + g0[n] + H[n,m] + H[n,j]);  psi2 partial [wg][m][j] += p;  W = p dLs[m][j] -> E;  v[n,m] += sum_j W
-__global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t N, const int M, double* __restrict__ E,
-                                                      const double* __restrict__ g0, const double* __restrict__ H,
-                                                      const double* __restrict__ dLs, double* __restrict__ p2_part,
-                                                      double* __restrict__ vrow) {
-  const int team = threadIdx.x >> 7, j = threadIdx.x & 127;
-  const bool act = j < M;
-  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * per;
-  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
-  double* __restrict__ pp = p2_part + (size_t)blockIdx.x * M * M;
-  for (int m = team; m < M; m += 2) {
-    const double dl = act ? dLs[(size_t)m * M + j] : 0.0;
-    double acc = 0.0;
-    for (int64_t n = r0; n < r1; ++n) {
-      double w = 0.0;
-      if (act) {
-        const size_t idx = ((size_t)n * M + m) * M + j;
-        const double p = exp(E[idx] + g0[n] + H[n * M + m] + H[n * M + j]);
-        acc += p;
-        w = p * dl;
-        E[idx] = w;
-      }
-      w = wave_sum_dpp(w);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&vrow[n * M + m], w);      // two addends per element: the order cannot matter
-    }
-    if (act) pp[(size_t)m * M + j] = acc;
-  }
-}
-
-// T[n, q0 + j] = sum_m z[m, q0 + j] Y[(n,m), j]
-__global__ void __launch_bounds__(128) wq_t_kernel(const int64_t N, const int M, const int QP, const int q0, const int qc,
-                                                    const double* __restrict__ Y, const double* __restrict__ Zc,
-                                                    double* __restrict__ T) {
-  const int j = threadIdx.x;
-  const int q = q0 + j;
-  if (j >= qc || q >= QP) return;
-  for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
-    double s = 0.0;
-    for (int m = 0; m < M; ++m) s += Zc[(size_t)m * QP + q] * Y[((size_t)n * M + m) * qc + j];
-    T[n * QP + q] = s;
-  }
-}
-
-// dZ3 partial [split][m][q0 + j] = sum over the split's rows n of d2[n, q0 + j] Y[(n,m), j]        (grid: M x splits)
-__global__ void __launch_bounds__(128) wq_dz3_kernel(const int64_t N, const int M, const int QP, const int q0, const int qc,
-                                                      const double* __restrict__ Y, const double* __restrict__ d2,
-                                                      double* __restrict__ part) {
-  const int j = threadIdx.x, m = blockIdx.x;
-  const int q = q0 + j;
-  if (j >= qc || q >= QP) return;
-  const int64_t per = (N + gridDim.y - 1) / gridDim.y;
-  const int64_t r0 = (int64_t)blockIdx.y * per;
-  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
-  double s = 0.0;
-  for (int64_t n = r0; n < r1; ++n) s += d2[n * QP + q] * Y[((size_t)n * M + m) * qc + j];
-  part[((size_t)blockIdx.y * M + m) * QP + q] = s;
-}
-
 // DM[n,q] = d2[n,q] mu[n,q]
 __global__ void __launch_bounds__(256) wq_dmu_kernel(int64_t n, const double* __restrict__ d2, const double* __restrict__ mu,
                                                       double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = d2[i] * mu[i];
+}
+
+// psi1 and the per-row part h of the psi2 exponent, for any Q, as four N x M x Q products on the right operand ZZ = [Z | Z^2 | 1]:
+//   P[n,m] = exp(g1[n] - 1/2 (e (Z^2)^T - 2 (e mu) Z^T));     H[n,m] = (d2 mu) Z^T - 1/4 d2 (Z^2)^T - 1/4 sum_q lam z[m,q]^2
+__global__ void __launch_bounds__(128) wq_ellq_kernel(const int M, const int QP, const double* __restrict__ Zc,
+                                                       const double* __restrict__ lam, double* __restrict__ ellq) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int q = 0; q < QP; ++q) { const double z = Zc[(size_t)m * QP + q]; s += 0.25 * lam[q] * z * z; }
+  ellq[m] = s;
+}
+
+__global__ void __launch_bounds__(256) wq_pfin_kernel(const int64_t NM, const int M, const double* __restrict__ g1,
+                                                       const double* __restrict__ ellq, double* __restrict__ P, double* __restrict__ H) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NM) return;
+  const int64_t n = i / M;
+  const int m = (int)(i - n * M);
+  P[i] = exp(g1[n] - 0.5 * P[i]);
+  H[i] -= ellq[m];
+}
+
+static void wq_psi1_fwd(hipStream_t s, const BigPlan& p, int64_t N, int M, BigWs& L, WqWs& X) {
+  const int QP = p.QP;
+  hipLaunchKernelGGL(wq_ellq_kernel, dim3((M + 127) / 128), dim3(128), 0, s, M, QP, L.zt.Zc, L.zt.lam, X.ellq);
+  hipLaunchKernelGGL(wq_dmu_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.rt.d2, L.rt.Xmu, X.DM);
+  const double* Z1 = L.ZZ;            // z      (M x QP inside rows of width W)
+  const double* Z2 = L.ZZ + QP;       // z^2
+  GemmArgs g;
+  g.m = (int)N; g.n = M; g.k = QP; g.lda = QP; g.ldb = p.W; g.tb = 1; g.ldc = M;
+  g.A = L.rt.e1; g.B = Z2; g.C = L.P;
+  launch_gemm(s, g);
+  g.A = L.rt.em; g.B = Z1; g.alpha = -2.0; g.gamma = 1.0; g.Cin = L.P; g.ldcin = M;
+  launch_gemm(s, g);
+  g.A = X.DM; g.B = Z1; g.C = L.H; g.alpha = 1.0; g.gamma = 0.0; g.Cin = nullptr;
+  launch_gemm(s, g);
+  g.A = L.rt.d2; g.B = Z2; g.alpha = -0.25; g.gamma = 1.0; g.Cin = L.H; g.ldcin = M;
+  launch_gemm(s, g);
+  hipLaunchKernelGGL(wq_pfin_kernel, dim3(big_nb256(N * M)), dim3(256), 0, s, N * M, M, L.rt.g1, X.ellq, L.P, L.H);
+}
+
+// pair tables: p = index of (a, b), a <= b, rows of the upper triangle one after the other
+__global__ void __launch_bounds__(256) wq_pairs_kernel(const int M, int* __restrict__ pa, int* __restrict__ pb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * M) return;
+  const int a = i / M, b = i % M;
+  if (b < a) return;
+  const int p = a * M - a * (a - 1) / 2 + (b - a);
+  pa[p] = a; pb[p] = b;
+}
+
+// ZZ2[q, p] = z[a,q] z[b,q]       (QP x P, the right operand of the Gram product and of the product that gives T)
+__global__ void __launch_bounds__(256) wq_zz2_kernel(const int P, const int QP, const int* __restrict__ pa, const int* __restrict__ pb,
+                                                      const double* __restrict__ Zc, double* __restrict__ ZZ2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)P * QP) return;
+  const int q = (int)(i / P), p = (int)(i - (int64_t)q * P);
+  ZZ2[i] = Zc[(size_t)pa[p] * QP + q] * Zc[(size_t)pb[p] * QP + q];
+}
+
+// The exponential pass over E[n, p] (N x P).  Workgroup = WQ_RB consecutive data rows, whose h rows and v accumulators are in
+// LDS; thread = one pair at a time, walking the block's rows:
+//   e = exp(E + g0[n] + h[n,a] + h[n,b]);  psi2 partial [wg][p] = sum_n e;  w = e dLs[a,b];  E <- c_p w  (c_p = 2 off the
+//   diagonal: one stored pair stands for two entries of the symmetric weights);  v[n,a] += w, v[n,b] += w (a != b)
+__global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t N, const int M, const int P, const int* __restrict__ pa,
+                                                      const int* __restrict__ pb, double* __restrict__ E,
+                                                      const double* __restrict__ g0, const double* __restrict__ H,
+                                                      const double* __restrict__ dLs, double* __restrict__ p2_part,
+                                                      double* __restrict__ vrow) {
+  extern __shared__ double wq_sm[];
+  double* hl = wq_sm;                       // [WQ_RB][M]
+  double* vl = wq_sm + WQ_RB * M;           // [WQ_RB][M]
+  double* gl = vl + WQ_RB * M;              // [WQ_RB]
+  const int64_t r0 = (int64_t)blockIdx.x * WQ_RB;
+  const int nr = (int)((N - r0 < WQ_RB) ? N - r0 : WQ_RB);
+  for (int i = threadIdx.x; i < nr * M; i += 256) { hl[i] = H[r0 * M + i]; vl[i] = 0.0; }
+  if (threadIdx.x < nr) gl[threadIdx.x] = g0[r0 + threadIdx.x];
+  __syncthreads();
+  double* __restrict__ pp = p2_part + (size_t)blockIdx.x * P;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int a = pa[p], b = pb[p];
+    const double dl = 0.5 * (dLs[(size_t)a * M + b] + dLs[(size_t)b * M + a]);
+    const double cp = (a == b) ? 1.0 : 2.0;
+    double* __restrict__ e = E + (size_t)r0 * P + p;
+    double acc = 0.0;
+    int n = 0;
+    for (; n + 4 <= nr; n += 4) {
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = e[(size_t)(n + u) * P] + gl[n + u] + hl[(n + u) * M + a] + hl[(n + u) * M + b];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = exp(x[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += x[u];
+        const double w = x[u] * dl;
+        e[(size_t)(n + u) * P] = cp * w;
+        atomicAdd(&vl[(n + u) * M + a], w);
+        if (a != b) atomicAdd(&vl[(n + u) * M + b], w);
+      }
+    }
+    for (; n < nr; ++n) {
+      const double x = exp(e[(size_t)n * P] + gl[n] + hl[n * M + a] + hl[n * M + b]);
+      acc += x;
+      const double w = x * dl;
+      e[(size_t)n * P] = cp * w;
+      atomicAdd(&vl[n * M + a], w);
+      if (a != b) atomicAdd(&vl[n * M + b], w);
+    }
+    pp[p] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr * M; i += 256) vrow[r0 * M + i] = vl[i];
+}
+
+// psi2[a,b] = psi2[b,a] = pair sums
+__global__ void __launch_bounds__(256) wq_sym_kernel(const int M, const int P, const int* __restrict__ pa, const int* __restrict__ pb,
+                                                      const double* __restrict__ pair, double* __restrict__ psi2) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int a = pa[p], b = pb[p];
+  const double v = pair[p];
+  psi2[(size_t)a * M + b] = v;
+  psi2[(size_t)b * M + a] = v;
+}
+
+// dZ3[m,q] = sum_m' z[m',q] sum_n d2[n,q] W[n,m,m'] from the split partials C[s][p][q] of (c o W)^T d2   (thread = (m, q))
+__global__ void __launch_bounds__(256) wq_dz3_kernel(const int M, const int P, const int QP, const int nsplit,
+                                                      const double* __restrict__ C, const double* __restrict__ Zc,
+                                                      double* __restrict__ dz3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * QP) return;
+  const int m = i / QP, q = i % QP;
+  double s = 0.0;
+  for (int mp = 0; mp < M; ++mp) {
+    const int a = mp < m ? mp : m, b = mp < m ? m : mp;
+    const size_t p = (size_t)a * M - (size_t)(a * (a - 1) / 2) + (b - a);
+    double c = 0.0;
+    for (int k = 0; k < nsplit; ++k) c += C[((size_t)k * P + p) * QP + q];
+    s += Zc[(size_t)mp * QP + q] * (mp == m ? c : 0.5 * c);
+  }
+  dz3[i] = s;
 }
 
 // Row gradients of the psi2 term from S22[n] = [a1 | vz2 | w | ..] = v[n,:] [Z | Z^2 | 1] and T (same expressions as the sweep
@@ -183,42 +221,38 @@ __global__ void __launch_bounds__(256) wq_dz2_kernel(int M, int QP, int Mld, con
 
 // psi2 forward sum, row gradients (added to L.gmu / L.gS), dz2, dlam2, wsum2 for a wide window
 static rgp_status wq_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, BigWs& L, WqWs& X) {
-  const int QP = p.QP;
-  const int64_t NM = N * M;
-  if (NM > 0x7fffffffLL) return rgp_fail(h, RGP_ERR_BAD_ARG, "wide windows: N * M exceeds 2^31 rows of the batched product");
-  const int nchunk = (QP + WQ_QC - 1) / WQ_QC;
-  const unsigned ablocks = (unsigned)((NM * WQ_QC + 255) / 256 < 65536 * 4 ? (NM * WQ_QC + 255) / 256 : 65536 * 4);
-  // gram: E = sum over the chunks of A_c Z_c^T
-  for (int c = 0; c < nchunk; ++c) {
-    const int q0 = c * WQ_QC, qc = (QP - q0 < WQ_QC) ? QP - q0 : WQ_QC;
-    hipLaunchKernelGGL(wq_a_kernel, dim3(ablocks), dim3(256), 0, s, NM, M, QP, q0, qc, L.dm, L.zt.Zc, X.A);
+  const int QP = p.QP, P = X.P;
+  hipLaunchKernelGGL(wq_pairs_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, X.pa, X.pb);
+  hipLaunchKernelGGL(wq_zz2_kernel, dim3(big_nb256((int64_t)P * QP)), dim3(256), 0, s, P, QP, X.pa, X.pb, L.zt.Zc, X.ZZ2);
+  {                                                          // Gram: E = dm ZZ2   (N x P, k = QP)
     GemmArgs g;
-    g.m = (int)NM; g.n = M; g.k = qc; g.A = X.A; g.lda = qc; g.B = L.zt.Zc + q0; g.ldb = QP; g.tb = 1; g.C = X.E; g.ldc = M;
-    if (c > 0) { g.gamma = 1.0; g.Cin = X.E; g.ldcin = M; }
+    g.m = (int)N; g.n = P; g.k = QP; g.A = L.dm; g.lda = QP; g.B = X.ZZ2; g.ldb = P; g.C = X.E; g.ldc = P;
     launch_gemm(s, g);
   }
-  // exponential pass: W in place of E, forward partial sums, v
-  hipLaunchKernelGGL(big_fill_kernel, dim3(big_nb256(NM)), dim3(256), 0, s, NM, X.vrow, 0.0);
-  hipLaunchKernelGGL(wq_exp_kernel, dim3(X.nexp), dim3(256), 0, s, N, M, X.E, L.rt.g0, L.H, L.dLs, X.p2w_part, X.vrow);
-  launch_reduce(s, X.nexp, (int64_t)M * M, (int64_t)M * M, X.p2w_part, L.psi2, 1.0, 0);
-  // back: per chunk Y = W Z_c, then the two reductions of Y
-  for (int c = 0; c < nchunk; ++c) {
-    const int q0 = c * WQ_QC, qc = (QP - q0 < WQ_QC) ? QP - q0 : WQ_QC;
+  // exponential pass: c o W in place of E, forward partial sums, v
+  hipLaunchKernelGGL(wq_exp_kernel, dim3(X.nexp), dim3(256), (2 * WQ_RB * M + WQ_RB) * sizeof(double), s, N, M, P, X.pa, X.pb,
+                     X.E, L.rt.g0, L.H, L.dLs, X.p2w_part, X.vrow);
+  launch_reduce(s, X.nexp, P, P, X.p2w_part, X.p2pair, 1.0, 0);
+  hipLaunchKernelGGL(wq_sym_kernel, dim3((P + 255) / 256), dim3(256), 0, s, M, P, X.pa, X.pb, X.p2pair, L.psi2);
+  {                                                          // T = (c o W) ZZ2^T   (N x QP, k = P)
     GemmArgs g;
-    g.m = (int)NM; g.n = qc; g.k = M; g.A = X.E; g.lda = M; g.B = L.zt.Zc + q0; g.ldb = QP; g.C = X.A; g.ldc = qc;
+    g.m = (int)N; g.n = QP; g.k = P; g.A = X.E; g.lda = P; g.B = X.ZZ2; g.ldb = P; g.tb = 1; g.C = X.T; g.ldc = QP;
     launch_gemm(s, g);
-    hipLaunchKernelGGL(wq_t_kernel, dim3((unsigned)(N < 8192 ? N : 8192)), dim3(128), 0, s, N, M, QP, q0, qc, X.A, L.zt.Zc, X.T);
-    hipLaunchKernelGGL(wq_dz3_kernel, dim3(M, X.nsplit), dim3(128), 0, s, N, M, QP, q0, qc, X.A, L.rt.d2, X.dz3_part);
   }
-  launch_reduce(s, X.nsplit, (int64_t)M * QP, (int64_t)M * QP, X.dz3_part, X.dz3, 1.0, 0);
+  {                                                          // C = (c o W)^T d2   (P x QP, k = N, split over the rows)
+    GemmArgs g;
+    g.m = P; g.n = QP; g.k = (int)N; g.A = X.E; g.lda = P; g.ta = 1; g.B = L.rt.d2; g.ldb = QP;
+    g.C = X.C_part; g.ldc = QP; g.splits = X.nsplit; g.split_stride = (int64_t)P * QP;
+    launch_gemm(s, g);
+  }
+  hipLaunchKernelGGL(wq_dz3_kernel, dim3((M * QP + 255) / 256), dim3(256), 0, s, M, P, QP, X.nsplit, X.C_part, L.zt.Zc, X.dz3);
   // from v alone: [a1 | vz2 | w] = V [Z | Z^2 | 1],  B1 = V^T (d2 o mu),  B2 = V^T d2
   {
     GemmArgs g;
     g.m = (int)N; g.n = p.W; g.k = M; g.A = X.vrow; g.lda = M; g.B = L.ZZ; g.ldb = p.W; g.C = X.S22; g.ldc = p.W;
     launch_gemm(s, g);
   }
-  hipLaunchKernelGGL(wq_dmu_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.rt.d2, L.rt.Xmu, X.DM);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2; ++k) {                              // X.DM = d2 o mu is still there from wq_psi1_fwd
     GemmArgs g;
     g.m = M; g.n = QP; g.k = (int)N; g.A = X.vrow; g.lda = M; g.ta = 1; g.B = k == 0 ? X.DM : L.rt.d2; g.ldb = QP;
     g.C = X.B_part; g.ldc = QP; g.splits = p.sk; g.split_stride = (int64_t)M * QP;
