@@ -178,14 +178,16 @@ def main():
         # algorithmic flops per (row, m, m') of the factorised form: Gram 2Q + y-update 2Q; the N*M*M exp evaluations are
         # listed separately (no fp64 transcendental unit: 14 VALU instructions each).
         flops = 4.0 * psi2_nmmq                      # 4 Q flop per (n, m, m')
+        if a.wide:                                   # executed count: three products over the M (M + 1) / 2 pairs, 2 N P Q flop each
+            flops = 3.0 * psi2_nmmq * (cfg['M'] + 1.0) / cfg['M']
         achieved = flops / (psi2_ms * 1e-3) / 1e12 if psi2_ms > 0 else 0.0
         nl = len(m.layers)
         if a.wide:
             metric = ('SVI steps/sec, 2-layer RGP M=100 T=4096 with 16-dimensional hidden layers (windows of 340/640/320 columns; '
                       'ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)')
-            kernel = ('gemm_f64_kernel (v_mfma_f64_16x16x4) inside the GEMM-shaped psi2 term: per 128-column chunk of the window one '
-                      'batched Gram product and one batched back product over the N x M x M weights in HBM; the time is that of the '
-                      'whole psi2 term of a layer (products + exp pass + reductions), 3 per step')
+            kernel = ('gemm_f64_large_kernel (v_mfma_f64_16x16x4, 128 x 128 tiles) inside the GEMM-shaped psi2 term: Gram product, T and C '
+                      'products over the N x P weights in HBM; the time is that of the whole psi2 term of a layer (three products + '
+                      'exp pass + reductions), 3 terms per step')
             traffic = None
             tnote = 'not collected for this workload'
         elif a.config == 4:
@@ -212,15 +214,20 @@ def main():
             'step_ms_main_stream': {'median': float(np.median(step_ms)), 'p10': float(np.percentile(step_ms, 10)),
                                     'p90': float(np.percentile(step_ms, 90)),
                                     'note': 'HIP events on the main stream between consecutive steps (rank 0); value uses the wall clock over all steps'},
-            'roofline': {'bound': 'mfma', 'bound_note': 'fp64 VALU: the contract offers hbm|mfma; on MI355X the fp64 matrix pipe shares the vector '
+            'roofline': {'bound': 'mfma', 'bound_note': 'fp64 MFMA (v_mfma_f64_16x16x4): with windows in the hundreds of columns the contraction '
+                                                        'is three large matrix products' if a.wide else
+                                                        'fp64 VALU: the contract offers hbm|mfma; on MI355X the fp64 matrix pipe shares the vector '
                                                         'pipe\'s datapath and is slower (profiles/r1_f64_peak.txt), so the contraction runs as v_fma_f64',
                          'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_note': tnote,
                          'kernel': kernel,
                          'avg_launch_ms': psi2_ms / max(psi2_n, 1), 'launches': psi2_n,
                          'algorithmic_flop_per_launch': flops / max(psi2_n, 1),
-                         'note': 'flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
-                                 'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q'},
+                         'note': ('flop = 3*N*M*(M+1)*Q per psi2 term as executed: three N x P x Q products over the P = M(M+1)/2 pairs of '
+                                  'inducing rows (the dense factorised form counts 4*N*M*M*Q); measured fp64 MFMA ceiling of this chip: '
+                                  '49 TFLOP/s (profiles/r1_f64_peak.txt)') if a.wide else
+                                 ('flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
+                                  'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q')},
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, Us, Ys, m, mb, n_total, T)

@@ -194,6 +194,14 @@ rgp_status rgp_svi_chain(rgp_handle h, int64_t N, int M, int D, double qU_ratio,
                          double* logL_minus_KL, double* dL_dKmm, double* dL_dpsi2, double* Kinv_mu,
                          double* dL_dthetaL, double* gqU_m, double* gqU_W, double* gqU_a, double* woodbury_inv);
 
+/* The fp64 matrix product every GEMM-shaped part of the path runs on (np.dot / tdot / dtrmm-style products of
+ * svi_vardtc.py:88-169,197-215 once M > 128, the N x M x D products of layers.py:98-132 for wide outputs, the pair-indexed
+ * psi2 products of wide windows):  C[m x n] = alpha op(A) op(B) + gamma C, row-major, op(X) = X or X^T (ta / tb != 0; A is
+ * then stored k x m, B n x k).  splits > 1 cuts k into that many pieces whose partial products are summed in fixed order
+ * (gamma must then be 0).  C must not overlap A or B. */
+rgp_status rgp_matmul(rgp_handle h, int m, int n, int k, double alpha, const double* A, int lda, int ta, const double* B,
+                      int ldb, int tb, double gamma, double* C, int ldc, int splits);
+
 /* ---- free-run prediction with moment matching (Layer.freerun, autoreg/layers.py:1537-1571 + GPy _raw_predict) ------
  * For each of n_seq independent sequences: X[0..X_win) = init (or N(0,1) when init_* == NULL, layers.py:1545), then for
  * n = 0..steps-1 the input row [X[n..n+X_win) | U[u_skip+n .. u_skip+n+U_win)] (means AND variances) is pushed through

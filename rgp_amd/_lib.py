@@ -72,6 +72,8 @@ SYMBOLS = {
     'rgp_layer_prepare': (C.c_int, [C.c_void_p, C.POINTER(LayerIn)]),
     'rgp_layer_step': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), C.POINTER(LayerOut)]),
     'rgp_kuu': (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_double, c_dp]),
+    'rgp_matmul': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_int, c_dp, C.c_int, C.c_int,
+                             C.c_double, c_dp, C.c_int, C.c_int]),
     'rgp_psi_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     'rgp_psi_forward_static': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
     'rgp_psi_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double,

@@ -90,6 +90,23 @@ class Handle(object):
         self._check(self.lib.rgp_kuu(self.h, M, Q, _p(Z), _p(variance), _p(inv_l), jitter, _p(out)))
         return out
 
+    def matmul(self, A, B, ta=False, tb=False, alpha=1.0, gamma=0.0, out=None, splits=1):
+        """out = alpha op(A) op(B) + gamma out on the library's fp64 MFMA product (row-major 2-D tensors, rows may be strided)."""
+        _chk64(A, B, out)
+        for t in (A, B) + ((out,) if out is not None else ()):
+            assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1
+        m, k = (A.shape[1], A.shape[0]) if ta else A.shape
+        n = B.shape[0] if tb else B.shape[1]
+        assert (B.shape[1] if tb else B.shape[0]) == k
+        if out is None:
+            assert gamma == 0.0
+            out = self.new(m, n)
+        assert out.shape == (m, n)
+        dp = lambda t: C.c_void_p(t.data_ptr())
+        self._check(self.lib.rgp_matmul(self.h, m, n, k, alpha, dp(A), A.stride(0), int(ta), dp(B), B.stride(0), int(tb), gamma,
+                                        dp(out), out.stride(0), splits))
+        return out
+
     def psi_forward(self, mu, S, Z, variance, inv_l, want_psi1=True, want_psi2=True):
         _chk64(mu, S, Z, variance, inv_l)
         N, Q = mu.shape

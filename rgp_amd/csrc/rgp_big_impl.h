@@ -95,7 +95,7 @@ static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q)
   Q.P = P;
   Q.nexp = (int)((N + WQ_RB - 1) / WQ_RB);
   if (Q.nexp < 1) Q.nexp = 1;
-  const int tiles = ((P + 63) / 64) * ((p.QP + 63) / 64);
+  const int tiles = ((P + 127) / 128) * ((p.QP + 127) / 128);  // 128 x 128 output tiles of the row-split product C
   Q.nsplit = (2048 + tiles - 1) / tiles;
   if (Q.nsplit > 16) Q.nsplit = 16;
   Q.E = ws.take<double>((size_t)N * P);

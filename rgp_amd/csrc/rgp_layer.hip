@@ -807,6 +807,36 @@ extern "C" rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const
   return last_launch(h, "rgp_kuu");
 }
 
+extern "C" rgp_status rgp_matmul(rgp_handle h, int m, int n, int k, double alpha, const double* A, int lda, int ta,
+                                 const double* B, int ldb, int tb, double gamma, double* C, int ldc, int splits) {
+  if (!h) return RGP_ERR_BAD_ARG;
+  if (m < 1 || n < 1 || k < 0 || !A || !B || !C) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_matmul: bad shape or null operand");
+  if (lda < (ta ? m : k) || ldb < (tb ? k : n) || ldc < n) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_matmul: leading dimension too small");
+  if (splits > 1 && gamma != 0.0) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_matmul: a split product cannot accumulate into C");
+  if (splits > 64) return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_matmul: at most 64 splits");
+  GemmArgs g;
+  g.m = m; g.n = n; g.k = k; g.A = A; g.lda = lda; g.ta = ta != 0; g.B = B; g.ldb = ldb; g.tb = tb != 0; g.alpha = alpha;
+  if (splits > 1) {
+    const size_t mn = (size_t)m * n;
+    rgp_status st = rgp_ensure_ws(h, (size_t)splits * mn * sizeof(double) + 256);
+    if (st) return st;
+    double* part = reinterpret_cast<double*>(h->ws);
+    g.C = part; g.ldc = n; g.splits = splits; g.split_stride = (int64_t)mn;
+    launch_gemm(h->stream, g);
+    if (ldc == n) launch_reduce(h->stream, splits, (int64_t)mn, (int64_t)mn, part, C, 1.0, 0);
+    else {
+      launch_reduce(h->stream, splits, (int64_t)mn, (int64_t)mn, part, part, 1.0, 0);       // element i reads only part[g * mn + i]
+      RGP_HIP_CHECK(h, hipMemcpy2DAsync(C, (size_t)ldc * sizeof(double), part, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                                        (size_t)m, hipMemcpyDeviceToDevice, h->stream));
+    }
+  } else {
+    g.C = C; g.ldc = ldc; g.gamma = gamma;
+    if (gamma != 0.0) { g.Cin = C; g.ldcin = ldc; }
+    launch_gemm(h->stream, g);
+  }
+  return last_launch(h, "rgp_matmul");
+}
+
 extern "C" rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S,
                                       const double* Z, const double* variance, const double* inv_l, double* psi1,
                                       double* psi2) {
