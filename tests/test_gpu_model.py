@@ -17,10 +17,11 @@ def make_data(n_seq, T, u_dim=2, y_dim=3, seed=0, ragged=False):
 
 
 def build_pair(n_seq=3, T=14, wins=(0, 3, 3), nDims=(3, 2, 3), M=4, U_win=2, seed=0, ragged=False, n_total=None,
-               u_dim=2, y_dim=3, inference='svi', fast_psi=False, chunk=16):
+               u_dim=2, y_dim=3, inference='svi', fast_psi=False, chunk=16, data=None):
     from oracle import model as om
     from rgp_amd.model import DeepAutoreg
-    U, Y = make_data(n_seq, T, u_dim, y_dim, seed, ragged)
+    U, Y = data if data is not None else make_data(n_seq, T, u_dim, y_dim, seed, ragged)
+    n_seq = len(Y)
     o = om.DeepAutoreg(list(wins), Y, U=U, U_win=U_win, nDims=list(nDims), X_variance=0.05, num_inducing=M, init='Y',
                        inference_method=inference, n_total=n_total, rng=np.random.default_rng(seed + 1), fast_psi=fast_psi,
                        chunk=chunk)

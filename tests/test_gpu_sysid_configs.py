@@ -1,0 +1,45 @@
+"""BASELINE configs 1 and 2 at their own geometry and on their own data (tests/golden/sysid_data.npz, written by
+tests/golden/make_sysid_data.py from the reference's data files): device against the oracle.
+  config 1: Actuator, one hidden layer, wins [0, 10], U_win 10, M = 20, the 512-sample training split, full batch, collapsed bound
+            (examples/IdentificationTraining_Actuator.ipynb; split and windows: autoreg/benchmark/tasks.py:141-158)
+  config 2: Ballbeam, two hidden layers, wins [0, 20, 20], U_win 20, M = 50, the 500-sample training split
+            (examples/IdentificationTraining_Ballbeam.ipynb overrides the task's window of 10 to 20)
+ELBO to 1e-11, every gradient group to 1e-9 of its largest entry; free-run over the held-out split: means to 1e-8, variances to
+1e-7 (layers.py:1537-1571)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_model import build_pair, compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _series(name):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sysid_data.npz'))
+    u, y, k = z[name + '_u'], z[name + '_y'], int(z[name + '_split'])
+    mu_u, sd_u, mu_y, sd_y = u[:k].mean(), u[:k].std(), y[:k].mean(), y[:k].std()      # normalised by the training split
+    u, y = (u - mu_u) / sd_u, (y - mu_y) / sd_y
+    return (u[:k], y[:k]), (u[k:], y[k:])
+
+
+CONFIGS = {
+    'actuator': dict(wins=(0, 10), nDims=(1, 1), M=20, U_win=10),
+    'ballbeam': dict(wins=(0, 20, 20), nDims=(1, 1, 1), M=50, U_win=20),
+}
+
+
+@pytest.mark.parametrize('name', ['actuator', 'ballbeam'])
+@pytest.mark.parametrize('inference', [None, 'svi'])
+def test_config_geometry_on_its_data(name, inference):
+    (u, y), (u_test, y_test) = _series(name)
+    o, g = build_pair(data=([u], [y]), inference=inference, fast_psi=True, chunk=128, seed=5, **CONFIGS[name])
+    compare(o, g)
+    # free-run over the held-out controls from the posterior the step above left behind
+    want, got = o.freerun(u_test), g.freerun(u_test)
+    g.handle.sync()
+    for (wm, wv), (gm, gv) in zip(want, got):
+        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
+    assert np.isfinite(got[-1][0][0].cpu().numpy()).all() and len(got[-1][0][0]) > 0 and y_test.shape[0] > 0
