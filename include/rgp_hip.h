@@ -124,7 +124,11 @@ rgp_status rgp_set_deterministic(rgp_handle h, int on);
 int        rgp_side_streams_independent(rgp_handle h);
 
 /* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,
- *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------ */
+ *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------
+ * Sizes (Q = X_win*X_dim + U_win*U_dim; RGP_ERR_BAD_ARG beyond): D <= 64;
+ *   M <= 128,  Q <= 64  : both modes, fused kernels, side-stream pipelining (rgp_layer_prepare);
+ *   M <= 1024, Q <= 64  : RGP_MODE_SVI, blocked kernels (steps run whole on the handle's stream; rgp_layer_prepare is a no-op);
+ *   M <= 128,  Q <= 1024: RGP_MODE_SVI, the psi2 term as large fp64 matrix products over the pairs of inducing rows (likewise). */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);
 
 /* ---- pipelining consecutive SVI steps -------------------------------------------------------------------------------
@@ -207,7 +211,8 @@ rgp_status rgp_matmul(rgp_handle h, int m, int n, int k, double alpha, const dou
  * n = 0..steps-1 the input row [X[n..n+X_win) | U[u_skip+n .. u_skip+n+U_win)] (means AND variances) is pushed through
  * the layer's posterior (woodbury_inv M x M, woodbury_vector M x D from rgp_layer_step) and the predictive mean/variance
  * become X[X_win+n] (variance clipped at 1e-15; <= 0 -> 1e-10, layers.py:1570).  X_dim == D.
- * Layouts: init_* [n_seq][X_win*D]; U_* [n_seq][u_rows][U_dim] (U_var NULL -> u_var_const); X_* [n_seq][X_win+steps][D]. */
+ * Layouts: init_* [n_seq][X_win*D]; U_* [n_seq][u_rows][U_dim] (U_var NULL -> u_var_const); X_* [n_seq][X_win+steps][D].
+ * Sizes: Q = X_win*D + U_win*U_dim <= 64 with M <= 1024, or Q <= 1024 with M <= 128 (RGP_ERR_BAD_ARG beyond). */
 rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_win, int U_win, int U_dim, int steps,
                        const double* Z, const double* variance, const double* inv_l, const double* woodbury_inv,
                        const double* woodbury_vector, const double* init_mean, const double* init_var,

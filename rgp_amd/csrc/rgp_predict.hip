@@ -272,6 +272,137 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_big_kernel(FreerunArgs a, 
   }
 }
 
+// Windows wider than 64 columns (any padded Q up to FRW_MAX_QP, M <= 128): the Gram terms of a step,
+// c[m,m'] = sum_q dml[q] z[m,q] z[m',q], no longer fit a register copy of z[m,:], so thread (m, part) keeps the FRW_MP
+// accumulators of its part of the m' sweep in registers and walks q once, reading z from the transposed copy ZcT[q][128]
+// (its own entry coalesced, the part's entries wave-uniform); the input row's terms are in dynamic LDS (4 x QP doubles).
+// Same arithmetic as freerun_kernel.
+#define FRW_MP 32
+#define FRW_MAX_QP 1024
+__global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a, const int QP, const double* __restrict__ ZcT,
+                                                                   const double* __restrict__ wv_g,
+                                                                   const double* __restrict__ winv_g) {
+  extern __shared__ double frw_rows[];
+  double* d2s = frw_rows;
+  double* dmls = frw_rows + QP;
+  double* e1s = frw_rows + 2 * QP;
+  double* mus = frw_rows + 3 * QP;
+  __shared__ double hbuf[RGP_PSI2_TEAM], p1buf[RGP_PSI2_TEAM];
+  __shared__ double red[8][FR_DC + 2];
+  __shared__ double scratch[16];
+  const int M = a.M, Q = a.Q, D = a.D;
+  const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1);
+  const int part = __builtin_amdgcn_readfirstlane(t >> 7);            // 4 parts
+  const bool act = tr < M;
+  const int tm = act ? tr : M - 1;
+  const int seq = blockIdx.x;
+  const int Mq = (M + 3) / 4;
+  const int mp0 = part * Mq, mp1 = (mp0 + Mq < M) ? mp0 + Mq : M;
+  const int Qx = a.X_win * a.X_dim;
+  const int64_t T_out = a.X_win + a.steps;
+  double* Xm = a.X_mean + (size_t)seq * T_out * a.X_dim;
+  double* Xv = a.X_var + (size_t)seq * T_out * a.X_dim;
+  const double* Um = a.U_mean ? a.U_mean + ((size_t)seq * a.u_rows + a.u_skip) * a.U_dim : nullptr;
+  const double* Uv = a.U_var ? a.U_var + ((size_t)seq * a.u_rows + a.u_skip) * a.U_dim : nullptr;
+  const double var = a.variance[0], logvar = log(var);
+
+  for (int i = t; i < Qx; i += FR_THREADS) {
+    Xm[i] = a.init_mean ? a.init_mean[(size_t)seq * Qx + i] : 0.0;
+    Xv[i] = a.init_var ? a.init_var[(size_t)seq * Qx + i] : 1.0;
+  }
+  double ellq = 0.0;
+  for (int q = 0; q < QP; ++q) {
+    const double z = ZcT[(size_t)q * RGP_PSI2_TEAM + tm];
+    ellq += 0.25 * a.lam[q] * z * z;
+  }
+  __syncthreads();
+
+  for (int n = 0; n < a.steps; ++n) {
+    // ---- the input row: [X[n .. n+X_win) | U[n .. n+U_win)] ----
+    double sl2 = 0.0, sl1 = 0.0, sdm = 0.0;
+    for (int q = t; q < QP; q += FR_THREADS) {
+      double mu = 0.0, d2 = 0.0, e1 = 0.0, dml = 0.0;
+      if (q < Q) {
+        double m, S;
+        if (q < Qx) { m = Xm[(size_t)n * a.X_dim + q]; S = Xv[(size_t)n * a.X_dim + q]; }
+        else { const int64_t i = (int64_t)n * a.U_dim + (q - Qx); m = Um[i]; S = Uv ? Uv[i] : a.u_var_const; }
+        const double lam = a.lam[q];
+        mu = m - a.c[q];
+        const double t2 = 1.0 + 2.0 * S * lam, t1 = 1.0 + S * lam;
+        d2 = lam / t2; e1 = lam / t1; dml = -2.0 * S * lam * d2;
+        sl2 += log(t2); sl1 += log(t1); sdm += d2 * mu * mu;
+      }
+      mus[q] = mu; d2s[q] = d2; e1s[q] = e1; dmls[q] = dml;
+    }
+    sl2 = block_sum(sl2, scratch); sl1 = block_sum(sl1, scratch); sdm = block_sum(sdm, scratch);
+    const double g0 = 2.0 * logvar - 0.5 * sl2 - sdm, g1 = logvar - 0.5 * sl1;
+    __syncthreads();
+    // ---- one walk over q: h, the psi1 exponent and the Gram terms of this thread's part of the sweep ----
+    double c[FRW_MP];
+#pragma unroll
+    for (int j = 0; j < FRW_MP; ++j) c[j] = 0.0;
+    double h = 0.0, e = 0.0;
+    for (int q = 0; q < QP; ++q) {
+      const double z = ZcT[(size_t)q * RGP_PSI2_TEAM + tm];
+      const double* __restrict__ zr = ZcT + (size_t)q * RGP_PSI2_TEAM + mp0;        // wave-uniform
+      const double aq = z * dmls[q];
+      h += z * d2s[q] * (mus[q] - 0.25 * z);
+      const double df = mus[q] - z;
+      e += e1s[q] * df * df;
+#pragma unroll
+      for (int j = 0; j < FRW_MP; ++j) c[j] += aq * zr[j];
+    }
+    h -= ellq;
+    const double p1 = exp(g1 - 0.5 * e);
+    if (part == 0) { hbuf[tr] = h; p1buf[tr] = act ? p1 : 0.0; }
+    const double base = act ? (g0 + h) : -INFINITY;
+    __syncthreads();
+    // ---- sweep over m' (repeated per chunk of FR_DC outputs) ----
+    for (int d0 = 0; d0 < D; d0 += FR_DC) {
+      const int dc = (D - d0 < FR_DC) ? D - d0 : FR_DC;
+      double wvm[FR_DC], acc[FR_DC];
+#pragma unroll
+      for (int d = 0; d < FR_DC; ++d) { wvm[d] = (d < dc) ? wv_g[(size_t)tm * D + d0 + d] : 0.0; acc[d] = 0.0; }
+      double trc = 0.0;
+#pragma unroll
+      for (int j = 0; j < FRW_MP; ++j) {
+        const int mp = mp0 + j;
+        if (mp < mp1) {
+          const double* __restrict__ ws = wv_g + (size_t)mp * D + d0;
+          const double p = exp((base + hbuf[mp]) - 0.5 * c[j]);
+          const double tt = p - (act ? p1 : 0.0) * p1buf[mp];
+          trc += winv_g[(size_t)mp * M + tm] * p;
+#pragma unroll
+          for (int d = 0; d < FR_DC; ++d)
+            if (d < dc) acc[d] += tt * wvm[d] * ws[d];
+        }
+      }
+      const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+      for (int d = 0; d < FR_DC; ++d) {
+        const double s = wave_sum(acc[d]);
+        if (lane == 0) red[wave][d] = s;
+      }
+      {
+        const double s = wave_sum(trc);
+        if (lane == 0) red[wave][FR_DC] = s;
+      }
+      __syncthreads();
+      if (t < dc) {
+        double qf = 0.0, tr_ = 0.0, mean = 0.0;
+        for (int w = 0; w < 8; ++w) { qf += red[w][t]; tr_ += red[w][FR_DC]; }
+        for (int m = 0; m < M; ++m) mean += p1buf[m] * wv_g[(size_t)m * D + d0 + t];
+        double v = qf + var - tr_;
+        v = fmax(v, 1e-15);                               // GPy _raw_predict clip
+        if (v <= 0.0) v = 1e-10;                          // layers.py:1570
+        Xm[(size_t)(a.X_win + n) * a.X_dim + d0 + t] = mean;
+        Xv[(size_t)(a.X_win + n) * a.X_dim + d0 + t] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int QP>
 static void freerun_big_launch(hipStream_t s, const FreerunArgs& a) {
   hipLaunchKernelGGL((freerun_big_kernel<QP>), dim3(a.n_seq), dim3(FR_THREADS), 0, s, a, a.Zc, a.wv, a.winv);
@@ -290,8 +421,9 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   if (!h) return RGP_ERR_BAD_ARG;
   const int X_dim = D;
   const int Q = X_win * X_dim + U_win * U_dim;
-  if (M > FRB_MAX_M || rgp_qp(Q) > RGP_MAX_QP || Q <= 0)
-    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 1024 and 0 < Q <= 64 in this build");
+  const bool wide = rgp_qp(Q) > RGP_MAX_QP;
+  if (M > FRB_MAX_M || Q <= 0 || (wide && (M > RGP_MAX_M || rgp_qp(Q) > FRW_MAX_QP)))
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 1024 and 0 < Q <= 64, or M <= 128 and Q <= 1024, in this build");
   const bool big = M > RGP_MAX_M;
   if (U_win > 0 && (!U_mean || u_rows - u_skip < steps + U_win - 1))
     return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: not enough input rows for the requested steps");
@@ -311,7 +443,10 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   a.u_rows = u_rows; a.u_skip = u_skip; a.Zc = zt.Zc; a.lam = zt.lam; a.c = zt.c; a.variance = variance; a.winv = woodbury_inv;
   a.wv = woodbury_vector; a.init_mean = init_mean; a.init_var = init_var; a.U_mean = U_mean; a.U_var = U_var;
   a.u_var_const = u_var_const; a.X_mean = X_mean; a.X_var = X_var;
-  if (big) {
+  if (wide) {
+    hipLaunchKernelGGL(freerun_wide_kernel, dim3(n_seq), dim3(FR_THREADS), 4 * (size_t)QP * sizeof(double), h->stream, a, QP,
+                       zt.ZcT, a.wv, a.winv);
+  } else if (big) {
     switch (QP) {
 #define FRB(qp) case qp: freerun_big_launch<qp>(h->stream, a); break;
       FRB(8) FRB(16) FRB(20) FRB(24) FRB(32) FRB(40) FRB(48) FRB(56) FRB(64)
