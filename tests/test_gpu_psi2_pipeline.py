@@ -22,6 +22,10 @@ pytestmark = pytest.mark.gpu
     # the widest windows: Q = 60 (padded to 64: a z row no longer fits the scalar registers at once) and Q = 45 (padded to 48)
     dict(wins=(0, 30, 30), nDims=(2, 1, 1), n_seq=1, T=12040, M=20, U_win=30, u_dim=1, y_dim=2),
     dict(wins=(0, 15, 15), nDims=(2, 2, 1), n_seq=1, T=12017, M=33, U_win=15, u_dim=1, y_dim=2),
+    # row counts just above a whole number of iterations: 6 x 232 iterations of five rows + 10 more (most workgroups' last
+    # iteration is empty or ragged); and M = 50 (eight rows in flight): 9 x 232 iterations + 20 more
+    dict(wins=(0, 20, 20), nDims=(16, 1, 1), n_seq=1, T=7028, M=100, U_win=20, u_dim=1, y_dim=16),
+    dict(wins=(0, 20, 20), nDims=(1, 1, 1), n_seq=2, T=8450, M=50, U_win=20, u_dim=1, y_dim=1),
 ])
 def test_many_iterations_per_workgroup_match_oracle(cfg):
     o, g = build_pair(fast_psi=True, chunk=512, **cfg)
