@@ -188,8 +188,14 @@ def main():
             kernel = ('gemm_f64_large_kernel (v_mfma_f64_16x16x4, 128 x 128 tiles) inside the GEMM-shaped psi2 term: Gram product, T and C '
                       'products over the N x P weights in HBM; the time is that of the whole psi2 term of a layer (three products + '
                       'exp pass + reductions), 3 terms per step')
-            traffic = None
-            tnote = 'not collected for this workload'
+            try:
+                tw = json.load(open(os.path.join(ROOT, 'profiles', 'r2_wide_traffic.json')))
+                traffic = (tw['total_fetch_raw'] + tw['total_write']) * 1e9
+            except Exception:
+                traffic = None
+            tnote = ('bytes of ALL kernels of one layer step (the psi2 term is 3/4 of them), FETCH_SIZE as counted + WRITE_SIZE from separate '
+                     'rocprofv3 --pmc passes (profiles/r2_wide_traffic.json; 8-byte-per-lane reads: FETCH_SIZE uncalibrated, at most 2x); '
+                     'algorithmic: the 5.27 GB of N x P weights written once, rewritten once and read three times')
         elif a.config == 4:
             metric = 'SVI steps/sec, 2-layer RGP M=100 T=4096 (ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
             kernel = 'psi2_rowsP_kernel (fused psi2 forward+backward, packed teams, the two waves of a SIMD half a step apart, fp64 VALU, 3 launches per step: Q=40,40,20)'
