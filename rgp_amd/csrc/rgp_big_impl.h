@@ -83,30 +83,40 @@ static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
 }
 
 #define WQ_MAX_QP 1024        // widest padded window of the wide path (rgp_wideq_impl.h)
-#define WQ_RB 24              // data rows per workgroup of its exponential pass (two M-wide LDS rows each: 48 KB at M = 128)
+#define WQ_RB_MAX 24          // data rows per workgroup of its exponential pass (two M-wide LDS rows each, 60 KB at most)
+#define WQ_E_BYTES (6ull << 30)   // the N x P weights are held for this many bytes of data rows at a time
 struct WqWs {                 // what the wide-window psi2 term needs beyond the blocked path's buffers
-  double *E, *ZZ2, *vrow, *T, *DM, *S22, *p2w_part, *p2pair, *C_part, *dz3, *B_part, *B1, *B2, *ellq;
+  double *E, *ZZ2, *vrow, *T, *DM, *S22, *p2w_part, *p2pair, *C_part, *C, *dz3, *B_part, *B1, *B2, *ellq;
   int *pa, *pb;
-  int P, nexp, nsplit;
+  int P, rb, nsplit;
+  int64_t nc;                 // data rows per chunk
 };
 
 static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q) {
   const int P = M * (M + 1) / 2;
   Q.P = P;
-  Q.nexp = (int)((N + WQ_RB - 1) / WQ_RB);
-  if (Q.nexp < 1) Q.nexp = 1;
+  Q.rb = (7680 - WQ_RB_MAX) / (2 * M);
+  if (Q.rb > WQ_RB_MAX) Q.rb = WQ_RB_MAX;
+  if (Q.rb < 1) Q.rb = 1;
+  int64_t nc = (int64_t)(WQ_E_BYTES / ((size_t)P * sizeof(double)));
+  if (nc < 1024) nc = 1024;
+  if (const char* e = getenv("RGP_WQ_CHUNK_ROWS")) { const long v = atol(e); if (v > 0) nc = v; }     // tests: several chunks at small N
+  if (nc > N) nc = N;
+  Q.nc = nc;
+  const int64_t nexp = (nc + Q.rb - 1) / Q.rb;
   const int tiles = ((P + 127) / 128) * ((p.QP + 127) / 128);  // 128 x 128 output tiles of the row-split product C
   Q.nsplit = (2048 + tiles - 1) / tiles;
   if (Q.nsplit > 16) Q.nsplit = 16;
-  Q.E = ws.take<double>((size_t)N * P);
+  Q.E = ws.take<double>((size_t)nc * P);
   Q.ZZ2 = ws.take<double>((size_t)p.QP * P);
   Q.vrow = ws.take<double>((size_t)N * M);
   Q.T = ws.take<double>((size_t)N * p.QP);
   Q.DM = ws.take<double>((size_t)N * p.QP);
   Q.S22 = ws.take<double>((size_t)N * p.W);
-  Q.p2w_part = ws.take<double>((size_t)Q.nexp * P);
+  Q.p2w_part = ws.take<double>((size_t)nexp * P);
   Q.p2pair = ws.take<double>(P);
   Q.C_part = ws.take<double>((size_t)Q.nsplit * P * p.QP);
+  Q.C = ws.take<double>((size_t)P * p.QP);
   Q.dz3 = ws.take<double>((size_t)M * p.QP);
   Q.B_part = ws.take<double>((size_t)p.sk * M * p.QP);
   Q.B1 = ws.take<double>((size_t)M * p.QP);
@@ -747,7 +757,6 @@ static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok 
   if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
   if (rgp_qp(Q) > RGP_MAX_QP) {
     if (!wide_ok) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is supported by the SVI layer step only");
-    if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 needs M <= 128");
     if (rgp_qp(Q) > WQ_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 1024 is not supported by this build");
   }
   if (N > 0x7fffffffLL / 2) return rgp_fail(h, RGP_ERR_BAD_ARG, "more than 2^30 data rows in one call");

@@ -1,4 +1,4 @@
-// rgp_wideq_impl.h -- SVI layer step for windows wider than 64 columns (64 < padded Q <= 1024, M <= 128).  Included by
+// rgp_wideq_impl.h -- SVI layer step for windows wider than 64 columns (64 < padded Q <= 1024, any M <= 1024).  Included by
 // rgp_layer.hip after rgp_big_impl.h; entered from big_svi_layer_step.
 //
 // With Q in the hundreds the per-thread arrays of the sweep kernels (dzl[Q], y[Q]) cannot stay in registers, and the two
@@ -91,21 +91,22 @@ __global__ void __launch_bounds__(256) wq_zz2_kernel(const int P, const int QP, 
   ZZ2[i] = Zc[(size_t)pa[p] * QP + q] * Zc[(size_t)pb[p] * QP + q];
 }
 
-// The exponential pass over E[n, p] (N x P).  Workgroup = WQ_RB consecutive data rows, whose h rows and v accumulators are in
-// LDS; thread = one pair at a time, walking the block's rows:
+// The exponential pass over the rows [row0, row0 + nrows) whose weights E[n - row0, p] (nrows x P) are in memory.  Workgroup = rb
+// consecutive data rows, whose h rows and v accumulators are in LDS; thread = one pair at a time, walking the block's rows:
 //   e = exp(E + g0[n] + h[n,a] + h[n,b]);  psi2 partial [wg][p] = sum_n e;  w = e dLs[a,b];  E <- c_p w  (c_p = 2 off the
 //   diagonal: one stored pair stands for two entries of the symmetric weights);  v[n,a] += w, v[n,b] += w (a != b)
-__global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t N, const int M, const int P, const int* __restrict__ pa,
-                                                      const int* __restrict__ pb, double* __restrict__ E,
+__global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t row0, const int64_t nrows, const int rb, const int M, const int P,
+                                                      const int* __restrict__ pa, const int* __restrict__ pb, double* __restrict__ E,
                                                       const double* __restrict__ g0, const double* __restrict__ H,
                                                       const double* __restrict__ dLs, double* __restrict__ p2_part,
                                                       double* __restrict__ vrow) {
   extern __shared__ double wq_sm[];
-  double* hl = wq_sm;                       // [WQ_RB][M]
-  double* vl = wq_sm + WQ_RB * M;           // [WQ_RB][M]
-  double* gl = vl + WQ_RB * M;              // [WQ_RB]
-  const int64_t r0 = (int64_t)blockIdx.x * WQ_RB;
-  const int nr = (int)((N - r0 < WQ_RB) ? N - r0 : WQ_RB);
+  double* hl = wq_sm;                       // [rb][M]
+  double* vl = wq_sm + rb * M;              // [rb][M]
+  double* gl = vl + rb * M;                 // [rb]
+  const int64_t l0 = (int64_t)blockIdx.x * rb;                  // first row of the block within the chunk
+  const int nr = (int)((nrows - l0 < rb) ? nrows - l0 : rb);
+  const int64_t r0 = row0 + l0;
   for (int i = threadIdx.x; i < nr * M; i += 256) { hl[i] = H[r0 * M + i]; vl[i] = 0.0; }
   if (threadIdx.x < nr) gl[threadIdx.x] = g0[r0 + threadIdx.x];
   __syncthreads();
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t N, const int 
     const int a = pa[p], b = pb[p];
     const double dl = 0.5 * (dLs[(size_t)a * M + b] + dLs[(size_t)b * M + a]);
     const double cp = (a == b) ? 1.0 : 2.0;
-    double* __restrict__ e = E + (size_t)r0 * P + p;
+    double* __restrict__ e = E + (size_t)l0 * P + p;
     double acc = 0.0;
     int n = 0;
     for (; n + 4 <= nr; n += 4) {
@@ -224,28 +225,37 @@ static rgp_status wq_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t
   const int QP = p.QP, P = X.P;
   hipLaunchKernelGGL(wq_pairs_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, X.pa, X.pb);
   hipLaunchKernelGGL(wq_zz2_kernel, dim3(big_nb256((int64_t)P * QP)), dim3(256), 0, s, P, QP, X.pa, X.pb, L.zt.Zc, X.ZZ2);
-  {                                                          // Gram: E = dm ZZ2   (N x P, k = QP)
-    GemmArgs g;
-    g.m = (int)N; g.n = P; g.k = QP; g.A = L.dm; g.lda = QP; g.B = X.ZZ2; g.ldb = P; g.C = X.E; g.ldc = P;
-    launch_gemm(s, g);
+  // the N x P weights exist for X.nc data rows at a time; psi2 and C accumulate over the chunks, v and T are per row
+  int chunk = 0;
+  for (int64_t r0 = 0; r0 < N; r0 += X.nc, ++chunk) {
+    const int64_t nc = (N - r0 < X.nc) ? N - r0 : X.nc;
+    {                                                        // Gram: E = dm ZZ2   (nc x P, k = QP)
+      GemmArgs g;
+      g.m = (int)nc; g.n = P; g.k = QP; g.A = L.dm + r0 * QP; g.lda = QP; g.B = X.ZZ2; g.ldb = P; g.C = X.E; g.ldc = P;
+      launch_gemm(s, g);
+    }
+    // exponential pass: c o W in place of E, forward partial sums, v
+    const int nexp = (int)((nc + X.rb - 1) / X.rb);
+    hipLaunchKernelGGL(wq_exp_kernel, dim3(nexp), dim3(256), (2 * (size_t)X.rb * M + X.rb) * sizeof(double), s, r0, nc, X.rb, M, P,
+                       X.pa, X.pb, X.E, L.rt.g0, L.H, L.dLs, X.p2w_part, X.vrow);
+    launch_reduce(s, nexp, P, P, X.p2w_part, X.p2pair, 1.0, chunk > 0);
+    {                                                        // T = (c o W) ZZ2^T   (nc x QP, k = P)
+      GemmArgs g;
+      g.m = (int)nc; g.n = QP; g.k = P; g.A = X.E; g.lda = P; g.B = X.ZZ2; g.ldb = P; g.tb = 1; g.C = X.T + r0 * QP; g.ldc = QP;
+      launch_gemm(s, g);
+    }
+    {                                                        // C (+)= (c o W)^T d2   (P x QP, k = nc, split over the rows)
+      GemmArgs g;
+      g.m = P; g.n = QP; g.k = (int)nc; g.A = X.E; g.lda = P; g.ta = 1; g.B = L.rt.d2 + r0 * QP; g.ldb = QP;
+      g.C = X.C_part; g.ldc = QP; g.splits = X.nsplit; g.split_stride = (int64_t)P * QP;
+      if (X.nsplit == 1) g.C = X.C;
+      if (X.nsplit == 1 && chunk > 0) { g.gamma = 1.0; g.Cin = X.C; g.ldcin = QP; }
+      launch_gemm(s, g);
+      if (X.nsplit > 1) launch_reduce(s, X.nsplit, (int64_t)P * QP, (int64_t)P * QP, X.C_part, X.C, 1.0, chunk > 0);
+    }
   }
-  // exponential pass: c o W in place of E, forward partial sums, v
-  hipLaunchKernelGGL(wq_exp_kernel, dim3(X.nexp), dim3(256), (2 * WQ_RB * M + WQ_RB) * sizeof(double), s, N, M, P, X.pa, X.pb,
-                     X.E, L.rt.g0, L.H, L.dLs, X.p2w_part, X.vrow);
-  launch_reduce(s, X.nexp, P, P, X.p2w_part, X.p2pair, 1.0, 0);
   hipLaunchKernelGGL(wq_sym_kernel, dim3((P + 255) / 256), dim3(256), 0, s, M, P, X.pa, X.pb, X.p2pair, L.psi2);
-  {                                                          // T = (c o W) ZZ2^T   (N x QP, k = P)
-    GemmArgs g;
-    g.m = (int)N; g.n = QP; g.k = P; g.A = X.E; g.lda = P; g.B = X.ZZ2; g.ldb = P; g.tb = 1; g.C = X.T; g.ldc = QP;
-    launch_gemm(s, g);
-  }
-  {                                                          // C = (c o W)^T d2   (P x QP, k = N, split over the rows)
-    GemmArgs g;
-    g.m = P; g.n = QP; g.k = (int)N; g.A = X.E; g.lda = P; g.ta = 1; g.B = L.rt.d2; g.ldb = QP;
-    g.C = X.C_part; g.ldc = QP; g.splits = X.nsplit; g.split_stride = (int64_t)P * QP;
-    launch_gemm(s, g);
-  }
-  hipLaunchKernelGGL(wq_dz3_kernel, dim3((M * QP + 255) / 256), dim3(256), 0, s, M, P, QP, X.nsplit, X.C_part, L.zt.Zc, X.dz3);
+  hipLaunchKernelGGL(wq_dz3_kernel, dim3((M * QP + 255) / 256), dim3(256), 0, s, M, P, QP, 1, X.C, L.zt.Zc, X.dz3);
   // from v alone: [a1 | vz2 | w] = V [Z | Z^2 | 1],  B1 = V^T (d2 o mu),  B2 = V^T d2
   {
     GemmArgs g;

@@ -46,3 +46,23 @@ def test_wide_window_freerun_matches_oracle(cfg):
     for (wm, wv), (gm, gv) in zip(want, got):
         np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize('cfg', [
+    # more than 128 inducing points with wide windows (blocked chain + pair products): Q = 80 / 120 / 80, M = 150
+    dict(wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=150, U_win=40, u_dim=1, y_dim=2),
+    dict(wins=(0, 30, 4), nDims=(2, 2, 1), n_seq=2, T=50, M=260, U_win=4, u_dim=1, y_dim=2),      # Q = 8 / 66 / 30, M = 260
+])
+def test_wide_windows_with_many_inducing_points(cfg):
+    o, g = build_pair(fast_psi=True, chunk=16, **cfg)
+    compare(o, g, rtol=1e-8)
+
+
+def test_wide_windows_in_row_chunks(monkeypatch):
+    """The N x P weights held for 37 data rows at a time (psi2 and C accumulate over the chunks, the last chunk is ragged)."""
+    monkeypatch.setenv('RGP_WQ_CHUNK_ROWS', '37')
+    o, g = build_pair(fast_psi=True, chunk=64, wins=(0, 75, 75), nDims=(3, 2, 2), n_seq=3, T=110, M=9, U_win=75, u_dim=1, y_dim=3,
+                      ragged=True, n_total=5)
+    compare(o, g)
+    o, g = build_pair(fast_psi=True, chunk=16, wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=150, U_win=40, u_dim=1, y_dim=2)
+    compare(o, g, rtol=1e-8)
