@@ -82,6 +82,8 @@ def main():
     one_gpu = os.environ.get('RGP_BENCH_ONE_GPU') == '1'
     if one_gpu:
         local = 0
+        import faulthandler            # a stuck collective in this debugging mode ends the process with every thread's traceback
+        faulthandler.dump_traceback_later(int(os.environ.get('RGP_BENCH_WATCHDOG_S', '900')), exit=True)
     torch.cuda.set_device(local)
     # RGP_BENCH_FORCE_DIST=1 (debugging aid): a single rank still creates the RCCL process group and passes its all-reduce to
     # the step, so the collective's stream handling can be exercised on a one-GPU box
@@ -114,7 +116,12 @@ def main():
     m._Us_host = [u[:-1] for u in Us]
     init_like_reference(m, Ys)
     if world > 1:                      # identical global parameters everywhere (q(U) init depends on local data)
-        dist.broadcast(m.param_array[:m.n_global], src=0)
+        if one_gpu:                    # gloo: CPU tensors only
+            c = m.param_array[:m.n_global].cpu()
+            dist.broadcast(c, src=0)
+            m.param_array[:m.n_global].copy_(c)
+        else:
+            dist.broadcast(m.param_array[:m.n_global], src=0)
     allreduce = None
     if force_dist:
         allreduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
