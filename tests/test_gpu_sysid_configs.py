@@ -43,3 +43,29 @@ def test_config_geometry_on_its_data(name, inference):
         np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
     assert np.isfinite(got[-1][0][0].cpu().numpy()).all() and len(got[-1][0][0]) > 0 and y_test.shape[0] > 0
+
+
+def test_actuator_lbfgs_trajectory_and_heldout_rmse():
+    """Config 1 end to end, as the reference's notebook does it (m.optimize('bfgs') then free-run on the held-out split,
+    autoreg/benchmark/run.py:51-58): L-BFGS-B on the device objective follows L-BFGS-B on the oracle's objective (same start,
+    same iteration limit) to 1e-6 of the final objective, and the held-out free-run RMSE of the two agrees to 1e-4."""
+    from scipy.optimize import fmin_l_bfgs_b
+    (u, y), (u_test, y_test) = _series('actuator')
+    o, g = build_pair(data=([u], [y]), inference=None, fast_psi=True, chunk=128, seed=5, **CONFIGS['actuator'])
+    x0 = o.get_optimizer_array()
+    np.testing.assert_allclose(g.get_optimizer_array(), x0, rtol=0, atol=1e-12)
+    f0 = o.objective_and_grad(x0)[0]
+    xo, fo, _ = fmin_l_bfgs_b(o.objective_and_grad, x0, maxfun=30, maxiter=25)
+    xg, fg, _ = fmin_l_bfgs_b(g.objective_and_grad, x0, maxfun=30, maxiter=25)
+    assert fo < f0 and fg < f0
+    assert abs(fg - fo) <= 1e-6 * abs(fo), (fg, fo)
+    o.set_optimizer_array(xo); o.elbo_and_grads()               # posteriors at the optimised parameters
+    g.set_optimizer_array(xg); g.evaluate(); g.handle.sync()
+    U_win = CONFIGS['actuator']['U_win']
+    pm_o = o.freerun(u_test)[-1][0]
+    pm_g = g.freerun(u_test)[-1][0][0].cpu().numpy()
+    yt = y_test[-pm_o.shape[0]:] if pm_o.shape[0] <= y_test.shape[0] else y_test
+    k = min(len(yt), pm_o.shape[0])
+    rmse_o = float(np.sqrt(np.mean((pm_o[-k:] - yt[-k:]) ** 2)))
+    rmse_g = float(np.sqrt(np.mean((pm_g[-k:] - yt[-k:]) ** 2)))
+    assert np.isfinite(rmse_g) and abs(rmse_g - rmse_o) <= 1e-4 * rmse_o, (rmse_g, rmse_o)
