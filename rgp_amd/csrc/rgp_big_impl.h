@@ -136,9 +136,11 @@ struct BigWs {
   double *dzA_part, *dzA1, *dzA2, *dz1, *dlam1_part, *dlam1, *lsum1_part, *lsum1;
   double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
   int64_t *row_off, *own_pre, *up_pre;
+  double *r2, *T2, *PsiR_part, *PsiR, *dYvar_row;     // collapsed bound only
 };
 
-static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, int D, int n_seq, BigWs& L, SviChain* ch) {
+static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, int D, int n_seq, BigWs& L, SviChain* ch,
+                        VarDtcChain* vc = nullptr) {
   WsAlloc ws(base);
   const int QP = p.QP;
   const int Dd = D > 0 ? D : 1;
@@ -173,6 +175,11 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
   L.wide = QP > RGP_MAX_QP;
   if (L.wide) wq_carve(ws, p, N, M, L.wq);
+  if (vc) {
+    vardtc_chain_carve(*vc, ws);
+    L.r2 = ws.take<double>(N); L.T2 = ws.take<double>(nm); L.dYvar_row = ws.take<double>(N);
+    L.PsiR_part = ws.take<double>((size_t)p.sk * mm); L.PsiR = ws.take<double>(mm);
+  }
   return ws.off;
 }
 
@@ -958,4 +965,174 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
     RGP_HIP_CHECK(h, hipStreamWaitEvent(h->side_post, h->ev_stats, 0));
   }
   return last_launch(h, "rgp_layer_step (blocked)");
+}
+
+// ==================================================================================================================
+// collapsed-bound layer step for M > 128 (VarDTC.inference, vardtc.py:88-208): the blocked kernels around the blocked chain.
+// dL/dpsi2 depends on psi2, so the forward kernel runs before the chain and the backward kernel after it.
+// ==================================================================================================================
+// T = r2[n] P[n,m]   (left operand of PsiR = P^T diag(r2) P)
+__global__ void __launch_bounds__(256) big_vd_scale_rows_kernel(int64_t NM, int M, const double* __restrict__ r2,
+                                                                 const double* __restrict__ P, double* __restrict__ T) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NM) T[i] = r2[i / M] * P[i];
+}
+// Row part of the bound (vardtc.py:177-205) for uncertain outputs, one wave per row, T2 = psi1 G2:
+//   Lp[n,m] (= beta psi1 o (Ym v), already there) += beta^2 r2[n] psi1[n,m] T2[n,m];  dL_dYvar[n] = -beta/2 + beta^2/2 sum_m psi1 T2
+__global__ void __launch_bounds__(256) big_vd_rows_kernel(int64_t N, int M, const double* __restrict__ r2, const double* __restrict__ P,
+                                                           const double* __restrict__ T2, const double* __restrict__ beta_p,
+                                                           double* __restrict__ Lp, double* __restrict__ dYvar) {
+  const double beta = beta_p[0];
+  const int lane = threadIdx.x & 63;
+  const int64_t wpb = blockDim.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < N; r += (int64_t)gridDim.x * wpb) {
+    const double rr = r2[r];
+    double tp = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double pt = P[r * M + m] * T2[r * M + m];
+      tp += pt;
+      Lp[r * M + m] += beta * beta * rr * pt;
+    }
+    tp = wave_sum(tp);
+    if (lane == 0) dYvar[r] = -0.5 * beta + 0.5 * beta * beta * tp;
+  }
+}
+
+// phase 0: whole step with local statistics; 1: statistics only, packed into stats_io as [psi0sum, yry, psi2 (M*M), psi1Y (D*M),
+// PsiR (M*M)]; 2: finish with the (all-reduced) statistics in stats_io, N_global rows in total, replicated terms weighted by rep_w.
+// Phase 2 relies on the row terms, psi1 and h that phase 1 of the same layer left in the handle's workspace.
+static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out, int phase, double* stats_io,
+                                        int64_t N_global, double rep_w) {
+  const int M = in->M, D = in->D;
+  const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
+  const int64_t N = in->N;
+  rgp_status st = big_check(h, N, M, Q);
+  if (st) return st;
+  if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
+  if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
+  if (D < 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be positive");
+  const BigPlan p = big_plan(h, N, M, Q);
+  const int QP = p.QP;
+  BigWs L;
+  VarDtcChain c{};
+  c.N = N; c.M = M; c.D = D; c.y_uncertain = in->y_uncertain;
+  const size_t need = big_carve(nullptr, p, N, M, Q, D, in->n_seq, L, nullptr, &c);
+  if ((st = rgp_ensure_ws(h, need))) return st;
+  big_carve(h->ws, p, N, M, Q, D, in->n_seq, L, nullptr, &c);
+  hipStream_t s = h->stream;
+
+  WindowSpec w{};
+  w.n_seq = in->n_seq; w.X_win = in->X_win; w.X_dim = in->X_dim; w.U_win = in->U_win; w.U_dim = in->U_dim; w.D = D;
+  w.y_uncertain = in->y_uncertain; w.own_off = in->own_off; w.own_len = in->own_len; w.up_off = in->up_off;
+  w.up_len = in->up_len; w.row_off = L.row_off; w.own_mean = in->own_mean; w.own_var = in->own_var;
+  w.up_mean = in->up_mean; w.up_var = in->up_var; w.up_var_const = in->up_var_const;
+
+  const size_t mm = (size_t)M * M, dm_ = (size_t)D * M;
+  if (phase != 2) {
+  // tables, Z terms, row terms
+  hipLaunchKernelGGL(svi_tables_kernel, dim3(1), dim3(64), 0, s, in->n_seq, in->X_win, in->own_len,
+                     in->U_win > 0 ? in->up_len : nullptr, L.row_off, L.own_pre, L.up_pre, N, D, in->variance, in->noise,
+                     L.psi0sum, L.psi0coef);
+  launch_prep_z(s, M, Q, QP, in->Z, in->variance, in->inv_l, RGP_JITTER, L.zt);
+  hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
+  launch_rowprep_window(s, N, Q, w, in->variance, L.zt, L.rt, L.Ym, in->y_uncertain ? L.Yv : nullptr, L.yry_part);
+  launch_reduce(s, 2048, 1, 1, L.yry_part, L.yry, 1.0, 0);
+  hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
+
+  // statistics (vardtc.py:54-86): psi1, psi1^T Y, psi2, and for uncertain outputs PsiR = psi1^T diag(r^2) psi1
+  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
+  {
+    GemmArgs g;
+    g.m = D; g.n = M; g.k = (int)N; g.A = L.Ym; g.lda = D; g.ta = 1; g.B = L.P; g.ldb = M;
+    g.C = p.sk > 1 ? L.psi1Y_part : L.psi1Y; g.ldc = M; g.splits = p.sk; g.split_stride = (int64_t)D * M;
+    launch_gemm(s, g);
+    if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)D * M, (int64_t)D * M, L.psi1Y_part, L.psi1Y, 1.0, 0);
+  }
+  if (in->y_uncertain) {
+    hipLaunchKernelGGL(rowsum_kernel, dim3(big_nb256(N)), dim3(256), 0, s, N, D, L.Yv, L.r2);
+    hipLaunchKernelGGL(big_vd_scale_rows_kernel, dim3(big_nb256(N * M)), dim3(256), 0, s, N * M, M, L.r2, L.P, L.T2);
+    GemmArgs g;
+    g.m = M; g.n = M; g.k = (int)N; g.A = L.T2; g.lda = M; g.ta = 1; g.B = L.P; g.ldb = M;
+    g.C = p.sk > 1 ? L.PsiR_part : L.PsiR; g.ldc = M; g.splits = p.sk; g.split_stride = (int64_t)M * M;
+    launch_gemm(s, g);
+    if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)M * M, (int64_t)M * M, L.PsiR_part, L.PsiR, 1.0, 0);
+  }
+  if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2))) return st;
+  }
+  if (phase == 1) {                                  // hand the local statistics to the caller (vardtc.py:65-67 stub)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io, L.psi0sum, sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 1, L.yry, sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2, L.psi2, mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+    RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2 + mm, L.psi1Y, dm_ * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (in->y_uncertain) RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io + 2 + mm + dm_, L.PsiR, mm * sizeof(double), hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL(big_fill_kernel, dim3(big_nb256((int64_t)mm)), dim3(256), 0, s, (int64_t)mm, stats_io + 2 + mm + dm_, 0.0);
+    return last_launch(h, "rgp_vardtc_stats (blocked)");
+  }
+
+  // M x M algebra
+  c.Kj = L.zt.Kuu; c.noise = in->noise; c.psi0sum = L.psi0sum; c.psi1Y = L.psi1Y; c.psi2 = L.psi2; c.yry = L.yry;
+  c.PsiR = L.PsiR; c.winv = out->woodbury_inv; c.status = h->status;
+  if (phase == 2) {                                  // global statistics supplied by the caller
+    c.N = N_global; c.psi0sum = stats_io; c.yry = stats_io + 1; c.psi2 = stats_io + 2; c.psi1Y = stats_io + 2 + mm;
+    c.PsiR = stats_io + 2 + mm + dm_;
+  }
+  if ((st = launch_vardtc_chain(h, c))) return st;
+  hipLaunchKernelGGL(psi0_coef_beta_kernel, dim3(1), dim3(64), 0, s, N, D, c.beta, L.psi0coef);
+
+  // row gradients: Lp = psi1 o dL/dpsi1,  dL/dYmean = beta (psi1 v^T - Ym),  dL/dYvar
+  {                                                          // Lp = beta psi1 o (Ym v)                     (vardtc.py:179-181)
+    GemmArgs g;
+    g.m = (int)N; g.n = M; g.k = D; g.A = L.Ym; g.lda = D; g.B = c.vT; g.ldb = D; g.tb = 1; g.C = L.Lp; g.ldc = M;
+    g.a_dev = c.beta; g.E = L.P; g.lde = M;
+    launch_gemm(s, g);
+  }
+  if (in->y_uncertain) {
+    {                                                        // T2 = psi1 G2
+      GemmArgs g;
+      g.m = (int)N; g.n = M; g.k = M; g.A = L.P; g.lda = M; g.B = c.G2; g.ldb = M; g.C = L.T2; g.ldc = M;
+      launch_gemm(s, g);
+    }
+    hipLaunchKernelGGL(big_vd_rows_kernel, dim3((unsigned)(N < 4096 ? (N + 3) / 4 : 1024)), dim3(256), 0, s, N, M, L.r2, L.P, L.T2,
+                       c.beta, L.Lp, L.dYvar_row);
+    {                                                        // dL/dYmean = beta psi1 v^T - beta Ym           (vardtc.py:204)
+      GemmArgs g;
+      g.m = (int)N; g.n = D; g.k = M; g.A = L.P; g.lda = M; g.B = c.vT; g.ldb = D; g.C = L.dYm; g.ldc = D;
+      g.a_dev = c.beta; g.gamma = -1.0; g.g_dev = c.beta; g.Cin = L.Ym; g.ldcin = D;
+      launch_gemm(s, g);
+    }
+  }
+  launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
+  hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
+  if ((st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1))) return st;
+
+  // latent gradients
+  int npart = 0;
+  if (in->y_uncertain) {
+    LatentArgs a{};
+    a.w = w; a.QP = QP; a.own_rows = in->own_rows; a.own_pre = L.own_pre; a.gmu = L.gmu; a.gS = L.gS; a.dYm = L.dYm;
+    a.noise = in->noise; a.dYvar_row = L.dYvar_row; a.g_own_mean = out->g_own_mean; a.g_own_var = out->g_own_var;
+    a.elbo_part = L.elbo_part;
+    hipLaunchKernelGGL(own_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+    npart = LAT_BLOCKS;
+  }
+  if (out->g_up_mean && in->U_win > 0) {
+    UpArgs a{};
+    a.w = w; a.QP = QP; a.up_rows = in->up_rows; a.up_pre = L.up_pre; a.gmu = L.gmu; a.gS = L.gS;
+    a.g_up_mean = out->g_up_mean; a.g_up_var = out->g_up_var;
+    hipLaunchKernelGGL(up_latent_kernel, dim3(LAT_BLOCKS), dim3(256), 0, s, a);
+  }
+  {
+    FinalizeArgs f{};
+    f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = in->variance;
+    f.Kj = L.zt.Kuu; f.dKmm = c.dKmm; f.dLs = L.dLs; f.psi2 = L.psi2; f.dz1 = L.dz1; f.dz2 = L.dz2; f.dz2_ld = p.Mld;
+    f.dlam1 = L.dlam1; f.dlam2 = L.dlam2; f.lsum1 = L.lsum1; f.wsum2 = L.wsum2;
+    f.dk_scale = rep_w; f.psi0_coef = 0.0; f.psi0_dev = L.psi0coef; f.psi0_dev_scale = 1.0;
+    f.gZ = out->gZ; f.ginv_l = out->ginv_l; f.gvariance = out->gvariance;
+    launch_finalize(s, f, L.fin_dlrow, L.fin_gsum);
+  }
+  hipLaunchKernelGGL(finish_elbo_kernel, dim3(1), dim3(64), 0, s, c.bound, L.elbo_part, npart, c.dthetaL, out->elbo,
+                     out->gnoise, rep_w);
+  if (out->woodbury_vector)
+    RGP_HIP_CHECK(h, hipMemcpyAsync(out->woodbury_vector, c.vT, (size_t)M * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return last_launch(h, "rgp_layer_step (blocked, collapsed bound)");
 }

@@ -38,6 +38,7 @@ struct VarDtcChain {
   // workspace
   double *Linv, *A, *LLinv, *Li, *G2, *T1, *T2, *T3, *C, *R, *dKmm, *dLdpsi2, *bT, *vT, *Vb;
   double *scal, *bound, *dthetaL, *beta;
+  double *bigD = nullptr, *bigP = nullptr;           // M > 128 only: inverses of the diagonal blocks, panel buffer
   double *winv;                                      // optional output
   int* status;
 };

@@ -860,7 +860,88 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   }
 }
 
-size_t vardtc_chain_ws_doubles(int M, int D) { return (size_t)14 * M * M + 3 * (size_t)M * D + 64; }
+// ---- the same chain for M > 128: blocked factorisations, every product an MFMA GEMM launch, element-wise glue --------------
+// scal: [0] beta, [1] beta^2, [4] sum log diag LL (chol_big)
+__global__ void vd_scal_kernel(VarDtcChain c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double beta = 1.0 / fmax(c.noise[0], 1e-6);                 // vardtc.py:102
+    c.beta[0] = beta; c.scal[0] = beta; c.scal[1] = beta * beta;
+  }
+}
+// what 0: T1 = A + I;  1: T1 = D (Kinv - G2)  (Kinv in c.C);  2: R, dKmm, dL_dpsi2, woodbury_inv from T1, T3
+__global__ void __launch_bounds__(256) vd_elem_kernel(VarDtcChain c, int what) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int M = c.M;
+  if (i >= (int64_t)M * M) return;
+  const double Dd = (double)c.D;
+  if (what == 0) c.T1[i] = c.A[i] + ((i / M == i % M) ? 1.0 : 0.0);
+  else if (what == 1) c.T1[i] = Dd * (c.C[i] - c.G2[i]);
+  else {
+    const double beta = c.beta[0];
+    const double R = 0.5 * c.T1[i];
+    c.R[i] = R;
+    c.dKmm[i] = R - 0.5 * Dd * beta * c.T3[i];
+    c.dLdpsi2[i] = beta * R;
+    if (c.winv) c.winv[i] = c.C[i] - c.G2[i];
+  }
+}
+// bound and dL/dnoise from the traces (same expressions as the end of vardtc_chain_kernel)
+__global__ void __launch_bounds__(CH_THREADS) vd_final_kernel(VarDtcChain c) {
+  __shared__ double scratch[16];
+  const int M = c.M, D = c.D, t = threadIdx.x;
+  const double Dd = (double)D, Nd = (double)c.N, beta = c.beta[0];
+  double trC = 0.0, trA = 0.0, sR = 0.0;
+  for (int i = t; i < M * D; i += blockDim.x) trC += c.bT[i] * c.bT[i];
+  for (int i = t; i < M; i += blockDim.x) trA += c.A[(size_t)i * M + i];
+  for (int64_t i = t; i < (int64_t)M * M; i += blockDim.x) {
+    if (c.y_uncertain) trC += beta * beta * c.G2[i] * c.PsiR[i];
+    sR += c.R[i] * beta * c.psi2[i];
+  }
+  trC = block_sum(trC, scratch); trA = block_sum(trA, scratch); sR = block_sum(sR, scratch);
+  if (t == 0) {
+    const double psi0b = beta * c.psi0sum[0], YRY = beta * c.yry[0], ldLL = c.scal[4];
+    c.bound[0] = -0.5 * (Dd * (Nd * LOG_2PI - Nd * log(beta) + psi0b - trA) + YRY - trC) - Dd * ldLL;     // (:148-149)
+    c.dthetaL[0] = 0.5 * (YRY * beta + beta * Dd * psi0b - Nd * Dd * beta) - beta * sR - beta * trC;       // (:168)
+  }
+}
+
+static rgp_status vardtc_chain_big(rgp_handle h, const VarDtcChain& c, hipStream_t s) {
+  const int M = c.M, D = c.D;
+  const unsigned eb = nblocks256((int64_t)M * M);
+  rgp_status st;
+  hipLaunchKernelGGL(vd_scal_kernel, dim3(1), dim3(64), 0, s, c);
+  RGP_HIP_CHECK(h, hipMemcpyAsync(c.T3, c.Kj, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if ((st = chol_big(h, s, c.T3, M, c.bigD, c.bigP, nullptr, c.status))) return st;
+  trtri_big(s, c.T3, M, c.bigD, c.Linv, c.bigP);
+  // A = beta Linv psi2 Linv^T ; LL = chol(I + A)                                             (:120-125)
+  gemm(s, M, M, M, 1.0, c.Linv, M, false, c.psi2, M, false, 0.0, c.T1, M);
+  gemm(s, M, M, M, 1.0, c.T1, M, false, c.Linv, M, true, 0.0, c.A, M, c.scal + 0);
+  hipLaunchKernelGGL(vd_elem_kernel, dim3(eb), dim3(256), 0, s, c, 0);
+  if ((st = chol_big(h, s, c.T1, M, c.bigD, c.bigP, c.scal + 4, c.status))) return st;
+  trtri_big(s, c.T1, M, c.bigD, c.LLinv, c.bigP);
+  gemm(s, M, M, M, 1.0, c.LLinv, M, false, c.Linv, M, false, 0.0, c.Li, M);                  // Li = L^-1
+  gemm(s, M, M, M, 1.0, c.Li, M, true, c.Li, M, false, 0.0, c.G2, M);                        // G2 = Li^T Li
+  gemm(s, M, D, M, 1.0, c.Li, M, false, c.psi1Y, M, true, 0.0, c.bT, D, c.scal + 0);         // b^T (M x D)   (:130)
+  gemm(s, M, D, M, 1.0, c.Li, M, true, c.bT, D, false, 0.0, c.vT, D);                        // v^T           (:132)
+  gemm(s, M, M, M, 1.0, c.Linv, M, true, c.Linv, M, false, 0.0, c.C, M);                     // Kinv
+  hipLaunchKernelGGL(vd_elem_kernel, dim3(eb), dim3(256), 0, s, c, 1);
+  gemm(s, M, M, D, -1.0, c.vT, D, false, c.vT, D, true, 1.0, c.T1, M);
+  if (c.y_uncertain) {
+    gemm(s, M, M, M, 1.0, c.G2, M, false, c.PsiR, M, false, 0.0, c.T2, M);
+    gemm(s, M, M, M, -1.0, c.T2, M, false, c.G2, M, false, 1.0, c.T1, M, c.scal + 1);
+  }
+  gemm(s, M, M, M, 1.0, c.psi2, M, false, c.C, M, false, 0.0, c.T2, M);
+  gemm(s, M, M, M, 1.0, c.C, M, false, c.T2, M, false, 0.0, c.T3, M);
+  hipLaunchKernelGGL(vd_elem_kernel, dim3(eb), dim3(256), 0, s, c, 2);
+  hipLaunchKernelGGL(vd_final_kernel, dim3(1), dim3(CH_THREADS), 0, s, c);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("vardtc chain (blocked): ") + hipGetErrorString(e));
+  return RGP_OK;
+}
+
+size_t vardtc_chain_ws_doubles(int M, int D) {
+  return (size_t)14 * M * M + 3 * (size_t)M * D + 64 + (M > CH_MAX_M ? big_fact_doubles(M) + 64 : 0);
+}
 
 void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws) {
   const size_t mm = (size_t)c.M * c.M, md = (size_t)c.M * c.D;
@@ -869,10 +950,11 @@ void vardtc_chain_carve(VarDtcChain& c, WsAlloc& ws) {
   c.C = ws.take<double>(mm); c.R = ws.take<double>(mm); c.dKmm = ws.take<double>(mm); c.dLdpsi2 = ws.take<double>(mm);
   c.bT = ws.take<double>(md); c.vT = ws.take<double>(md); c.Vb = ws.take<double>(md);
   c.scal = ws.take<double>(8); c.bound = ws.take<double>(1); c.dthetaL = ws.take<double>(1); c.beta = ws.take<double>(1);
+  if (c.M > CH_MAX_M) big_fact_carve(c.M, c.bigD, c.bigP, ws);
 }
 
 rgp_status launch_vardtc_chain(rgp_handle h, const VarDtcChain& c) {
-  if (c.M > 128) return rgp_fail(h, RGP_ERR_BAD_ARG, "vardtc chain: M > 128 needs the blocked factorisation (not in this build)");
+  if (c.M > CH_MAX_M) return vardtc_chain_big(h, c, h->stream);
   size_t lds = ((size_t)c.M * (c.M + 1) + LDS_FACT_EXTRA) * sizeof(double);
   if (lds < 2 * GP_K * GP_LD * sizeof(double)) lds = 2 * GP_K * GP_LD * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)vardtc_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -777,7 +777,7 @@ static inline bool rgp_is_wide(const rgp_layer_in* in) { return rgp_qp(in->X_win
 
 static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
-  if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is supported by the SVI bound only (collapsed bound: M <= 128)");
+  if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 128 is not supported by this entry point");
   if (rgp_qp(Q) > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is not supported by this build");
   return RGP_OK;
 }
@@ -1007,6 +1007,7 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
+  if (rgp_is_big(M)) return big_vardtc_layer_step(h, in, out, phase, stats_io, N_global, rep_w);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");

@@ -176,17 +176,31 @@ def test_big_workspace_bytes_and_limits():
     m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=1025, inference_method='svi')   # M > 1024
     with pytest.raises(RgpError):
         m.evaluate()
-    m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=129, inference_method=None)    # collapsed bound: M <= 128
+    m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=1025, inference_method=None)   # collapsed bound likewise
     with pytest.raises(RgpError):
         m.evaluate()
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(wins=(0, 3, 3), nDims=(3, 2, 3), n_seq=3, T=14, M=129),                                              # toy geometry, just over the limit
+    dict(wins=(0, 20, 20), nDims=(5, 1, 1), n_seq=2, T=56, M=200, U_win=20, u_dim=1, y_dim=5, ragged=True),    # Q = 40 / 40 / 20
+    dict(wins=(0, 10), nDims=(64, 2), n_seq=1, T=60, M=300, U_win=10, u_dim=1, y_dim=64),                      # D = 64 observed, two-dimensional hidden layer
+])
+def test_big_collapsed_bound_matches_oracle(cfg):
+    """VarDTC (autoreg/inference/vardtc.py:88-208) with more than 128 inducing points: blocked psi kernels around the blocked
+    chain (Cholesky of K_uu and of I + A, their inverses, every product an MFMA GEMM)."""
+    from test_gpu_model import compare
+    o, g = _pair(inference=None, **cfg)
+    compare(o, g, rtol=1e-8)
+
+
+@pytest.mark.parametrize('inference', ['svi', None])
 @pytest.mark.parametrize('M', [129, 600])
-def test_big_freerun_matches_oracle(M):
+def test_big_freerun_matches_oracle(M, inference):
     """Moment-matching free-run (layers.py:1551-1571) with M > 128: the m' sweep split into parts (M <= 256) and inducing rows
     in blocks of 512 (M > 512)."""
     from test_gpu_model import compare
-    o, g = _pair(n_seq=2, T=16, M=M)
+    o, g = _pair(n_seq=2, T=16, M=M, inference=inference)
     compare(o, g, rtol=1e-6)        # hundreds of inducing points in 6 to 15 input dimensions: cond(K_uu) is at the jitter's limit
     U = np.random.default_rng(8).standard_normal((12, 2))
     want, got = o.freerun(U), g.freerun(U)

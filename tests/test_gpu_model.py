@@ -290,15 +290,17 @@ def test_streamer_and_checkpoint(tmp_path):
     assert g.objective_and_grad(g.get_optimizer_array())[0] == f_full
 
 
-def test_collapsed_bound_data_parallel_two_shards():
+@pytest.mark.parametrize('M', [4, 140])
+def test_collapsed_bound_data_parallel_two_shards(M):
     """Collapsed-bound data parallelism: two shards exchange only the sufficient statistics
     [psi0, yry, psi2, psi1Y, PsiR] per layer (the reference's dead allReduceArrays stub, svi_vardtc.py:65-67) and one sum of
-    [ELBO, global gradients] reproduces the single-device collapsed bound.  Two handles emulate the two ranks."""
+    [ELBO, global gradients] reproduces the single-device collapsed bound.  Two handles emulate the two ranks.  M = 140 takes
+    the blocked kernels and the blocked chain."""
     import torch
     from oracle import model as om
     from rgp_amd.model import DeepAutoreg
     U, Y = make_data(4, 13, seed=3)
-    kw = dict(U_win=2, nDims=[3, 2, 3], X_variance=0.05, num_inducing=4, init='Y', inference_method=None)
+    kw = dict(U_win=2, nDims=[3, 2, 3], X_variance=0.05, num_inducing=M, init='Y', inference_method=None)
     full = DeepAutoreg([0, 3, 3], Y, U=U, seed=0, **kw)
     A = DeepAutoreg([0, 3, 3], Y[:2], U=U[:2], seed=0, **kw)
     B = DeepAutoreg([0, 3, 3], Y[2:], U=U[2:], seed=0, **kw)
