@@ -128,7 +128,7 @@ int        rgp_side_streams_independent(rgp_handle h);
  * Sizes (Q = X_win*X_dim + U_win*U_dim; RGP_ERR_BAD_ARG beyond): D <= 64;
  *   M <= 128,  Q <= 64  : both modes, fused kernels, side-stream pipelining (rgp_layer_prepare);
  *   M <= 1024, Q <= 64  : both modes, blocked kernels (steps run whole on the handle's stream; rgp_layer_prepare is a no-op);
- *   M <= 1024, Q <= 1024: RGP_MODE_SVI, the psi2 term as large fp64 matrix products over the pairs of inducing rows (likewise;
+ *   M <= 1024, Q <= 1024: both modes, the psi2 term as large fp64 matrix products over the pairs of inducing rows (likewise;
  *                         the N x M(M+1)/2 weights are held in the workspace for about 6 GB of data rows at a time). */
 rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out);
 

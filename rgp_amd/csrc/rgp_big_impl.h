@@ -763,7 +763,7 @@ static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok 
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
   if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
   if (rgp_qp(Q) > RGP_MAX_QP) {
-    if (!wide_ok) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is supported by the SVI layer step only");
+    if (!wide_ok) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 64 is supported by the layer step and free-run only");
     if (rgp_qp(Q) > WQ_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "Q > 1024 is not supported by this build");
   }
   if (N > 0x7fffffffLL / 2) return rgp_fail(h, RGP_ERR_BAD_ARG, "more than 2^30 data rows in one call");
@@ -1006,7 +1006,7 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
-  rgp_status st = big_check(h, N, M, Q);
+  rgp_status st = big_check(h, N, M, Q, true);
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
   if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
@@ -1040,7 +1040,8 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
   hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
 
   // statistics (vardtc.py:54-86): psi1, psi1^T Y, psi2, and for uncertain outputs PsiR = psi1^T diag(r^2) psi1
-  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
+  if (L.wide) wq_psi1_fwd(s, p, N, M, L, L.wq);
+  else launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
   {
     GemmArgs g;
     g.m = D; g.n = M; g.k = (int)N; g.A = L.Ym; g.lda = D; g.ta = 1; g.B = L.P; g.ldb = M;
@@ -1057,7 +1058,9 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
     launch_gemm(s, g);
     if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)M * M, (int64_t)M * M, L.PsiR_part, L.PsiR, 1.0, 0);
   }
-  if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2))) return st;
+  st = L.wide ? wq_psi2_forward(h, s, p, N, M, L, L.wq)
+              : launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
+  if (st) return st;
   }
   if (phase == 1) {                                  // hand the local statistics to the caller (vardtc.py:65-67 stub)
     RGP_HIP_CHECK(h, hipMemcpyAsync(stats_io, L.psi0sum, sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1103,7 +1106,8 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
   }
   launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
   hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, c.dLdpsi2, L.dLs);
-  if ((st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1))) return st;
+  st = L.wide ? wq_psi2(h, s, p, N, M, Q, L, L.wq) : launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
+  if (st) return st;
 
   // latent gradients
   int npart = 0;

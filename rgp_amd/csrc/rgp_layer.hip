@@ -1007,7 +1007,7 @@ static rgp_status vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, const 
   const int M = in->M, D = in->D;
   const int Q = in->X_win * in->X_dim + in->U_win * in->U_dim;
   const int64_t N = in->N;
-  if (rgp_is_big(M)) return big_vardtc_layer_step(h, in, out, phase, stats_io, N_global, rep_w);
+  if (rgp_is_big(M) || rgp_is_wide(in)) return big_vardtc_layer_step(h, in, out, phase, stats_io, N_global, rep_w);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");

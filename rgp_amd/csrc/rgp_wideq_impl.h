@@ -107,17 +107,30 @@ __global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t row0, const i
   const int64_t l0 = (int64_t)blockIdx.x * rb;                  // first row of the block within the chunk
   const int nr = (int)((nrows - l0 < rb) ? nrows - l0 : rb);
   const int64_t r0 = row0 + l0;
+  const bool fwd_only = dLs == nullptr;                         // forward sums alone (collapsed bound: before the chain)
   for (int i = threadIdx.x; i < nr * M; i += 256) { hl[i] = H[r0 * M + i]; vl[i] = 0.0; }
   if (threadIdx.x < nr) gl[threadIdx.x] = g0[r0 + threadIdx.x];
   __syncthreads();
   double* __restrict__ pp = p2_part + (size_t)blockIdx.x * P;
   for (int p = threadIdx.x; p < P; p += 256) {
     const int a = pa[p], b = pb[p];
-    const double dl = 0.5 * (dLs[(size_t)a * M + b] + dLs[(size_t)b * M + a]);
-    const double cp = (a == b) ? 1.0 : 2.0;
     double* __restrict__ e = E + (size_t)l0 * P + p;
     double acc = 0.0;
     int n = 0;
+    if (fwd_only) {
+      for (; n + 4 <= nr; n += 4) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = e[(size_t)(n + u) * P] + gl[n + u] + hl[(n + u) * M + a] + hl[(n + u) * M + b];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += exp(x[u]);
+      }
+      for (; n < nr; ++n) acc += exp(e[(size_t)n * P] + gl[n] + hl[n * M + a] + hl[n * M + b]);
+      pp[p] = acc;
+      continue;
+    }
+    const double dl = 0.5 * (dLs[(size_t)a * M + b] + dLs[(size_t)b * M + a]);
+    const double cp = (a == b) ? 1.0 : 2.0;
     for (; n + 4 <= nr; n += 4) {
       double x[4];
 #pragma unroll
@@ -144,7 +157,8 @@ __global__ void __launch_bounds__(256) wq_exp_kernel(const int64_t row0, const i
     pp[p] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nr * M; i += 256) vrow[r0 * M + i] = vl[i];
+  if (!fwd_only)
+    for (int i = threadIdx.x; i < nr * M; i += 256) vrow[r0 * M + i] = vl[i];
 }
 
 // psi2[a,b] = psi2[b,a] = pair sums
@@ -218,6 +232,26 @@ __global__ void __launch_bounds__(256) wq_dz2_kernel(int M, int QP, int Mld, con
   if (i >= M * QP) return;
   const int m = i / QP, q = i % QP;
   dz2[(size_t)q * Mld + m] = 2.0 * B1[i] - Zc[i] * B2[i] - dZ3[i];
+}
+
+// psi2 forward sum alone (collapsed bound: dL/dpsi2 needs psi2 before the backward products can run)
+static rgp_status wq_psi2_forward(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, BigWs& L, WqWs& X) {
+  const int QP = p.QP, P = X.P;
+  hipLaunchKernelGGL(wq_pairs_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, X.pa, X.pb);
+  hipLaunchKernelGGL(wq_zz2_kernel, dim3(big_nb256((int64_t)P * QP)), dim3(256), 0, s, P, QP, X.pa, X.pb, L.zt.Zc, X.ZZ2);
+  int chunk = 0;
+  for (int64_t r0 = 0; r0 < N; r0 += X.nc, ++chunk) {
+    const int64_t nc = (N - r0 < X.nc) ? N - r0 : X.nc;
+    GemmArgs g;
+    g.m = (int)nc; g.n = P; g.k = QP; g.A = L.dm + r0 * QP; g.lda = QP; g.B = X.ZZ2; g.ldb = P; g.C = X.E; g.ldc = P;
+    launch_gemm(s, g);
+    const int nexp = (int)((nc + X.rb - 1) / X.rb);
+    hipLaunchKernelGGL(wq_exp_kernel, dim3(nexp), dim3(256), (2 * (size_t)X.rb * M + X.rb) * sizeof(double), s, r0, nc, X.rb, M, P,
+                       X.pa, X.pb, X.E, L.rt.g0, L.H, (const double*)nullptr, X.p2w_part, X.vrow);
+    launch_reduce(s, nexp, P, P, X.p2w_part, X.p2pair, 1.0, chunk > 0);
+  }
+  hipLaunchKernelGGL(wq_sym_kernel, dim3((P + 255) / 256), dim3(256), 0, s, M, P, X.pa, X.pb, X.p2pair, L.psi2);
+  return last_launch(h, "psi2 forward (wide windows)");
 }
 
 // psi2 forward sum, row gradients (added to L.gmu / L.gS), dz2, dlam2, wsum2 for a wide window

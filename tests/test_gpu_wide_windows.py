@@ -66,3 +66,15 @@ def test_wide_windows_in_row_chunks(monkeypatch):
     compare(o, g)
     o, g = build_pair(fast_psi=True, chunk=16, wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=150, U_win=40, u_dim=1, y_dim=2)
     compare(o, g, rtol=1e-8)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=12, U_win=40, u_dim=1, y_dim=2),        # Q = 80 / 120 / 80
+    dict(wins=(0, 30, 4), nDims=(2, 2, 1), n_seq=2, T=50, M=100, U_win=4, u_dim=1, y_dim=2),         # a wide layer between narrow ones
+    dict(wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=150, U_win=40, u_dim=1, y_dim=2),       # with the blocked chain
+])
+def test_wide_windows_collapsed_bound(cfg):
+    """VarDTC with windows wider than 64 columns: the pair-indexed Gram + exp pass runs once for psi2 before the chain and the
+    full set of products after it."""
+    o, g = build_pair(fast_psi=True, chunk=16, inference=None, **cfg)
+    compare(o, g, rtol=1e-8)
