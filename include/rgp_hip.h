@@ -167,7 +167,8 @@ rgp_status rgp_vardtc_stats(rgp_handle h, const rgp_layer_in* in, double* stats)
 rgp_status rgp_vardtc_finish(rgp_handle h, const rgp_layer_in* in, const rgp_layer_out* out, double* stats,
                              int64_t N_global, double replicated_weight);
 
-/* ---- unit-testable pieces (dense, caller-materialised X; replace the GPy kernel protocol) -------------------- */
+/* ---- unit-testable pieces (dense, caller-materialised X; replace the GPy kernel protocol) --------------------
+ * Sizes: M <= 1024, Q <= 1024 (the kernels are picked by size as in rgp_layer_step). */
 /* kern.K(Z) + jitter*I (vardtc.py:110-114). */
 rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,
                    double jitter, double* Kuu);

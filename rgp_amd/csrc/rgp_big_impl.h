@@ -775,7 +775,7 @@ static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok 
 // ==================================================================================================================
 static rgp_status big_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
                                   const double* variance, const double* inv_l, double* psi1, double* psi2) {
-  rgp_status st = big_check(h, N, M, Q);
+  rgp_status st = big_check(h, N, M, Q, true);
   if (st) return st;
   const BigPlan p = big_plan(h, N, M, Q);
   BigWs L;
@@ -785,6 +785,17 @@ static rgp_status big_psi_forward(rgp_handle h, int64_t N, int M, int Q, const d
   hipStream_t s = h->stream;
   launch_prep_z(s, M, Q, p.QP, Z, variance, inv_l, RGP_JITTER, L.zt);
   launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
+  if (L.wide) {                                              // windows wider than 64 columns: the GEMM-shaped forms
+    hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, p.QP, p.W, L.zt.Zc, L.ZZ);
+    wq_psi1_fwd(s, p, N, M, L, L.wq);
+    if (psi1) RGP_HIP_CHECK(h, hipMemcpyAsync(psi1, L.P, (size_t)N * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (psi2) {
+      hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * p.QP)), dim3(256), 0, s, N * p.QP, p.QP, L.rt.d2, L.zt.lam, L.dm);
+      if ((st = wq_psi2_forward(h, s, p, N, M, L, L.wq))) return st;
+      RGP_HIP_CHECK(h, hipMemcpyAsync(psi2, L.psi2, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    return last_launch(h, "rgp_psi_forward (wide windows)");
+  }
   launch_big_psi1_fwd(s, N, M, L.zt, L.rt, psi1, psi2 ? L.H : nullptr);
   if (psi2) {
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * p.QP)), dim3(256), 0, s, N * p.QP, p.QP, L.rt.d2, L.zt.lam, L.dm);
@@ -802,7 +813,7 @@ __global__ void __launch_bounds__(256) big_mul_kernel(int64_t n, const double* _
 static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
                                    const double* variance, const double* inv_l, double dL_dpsi0_sum, const double* dL_dpsi1,
                                    const double* dL_dpsi2, double* dvar, double* dinv_l, double* dZ, double* dmu, double* dS) {
-  rgp_status st = big_check(h, N, M, Q);
+  rgp_status st = big_check(h, N, M, Q, true);
   if (st) return st;
   const BigPlan p = big_plan(h, N, M, Q);
   BigWs L;
@@ -813,9 +824,10 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
   const int QP = p.QP;
   launch_prep_z(s, M, Q, QP, Z, variance, inv_l, RGP_JITTER, L.zt);
   launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
-  launch_big_psi1_fwd(s, N, M, L.zt, L.rt, dL_dpsi1 ? L.P : nullptr, dL_dpsi2 ? L.H : nullptr);
+  hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
+  if (L.wide) wq_psi1_fwd(s, p, N, M, L, L.wq);
+  else launch_big_psi1_fwd(s, N, M, L.zt, L.rt, dL_dpsi1 ? L.P : nullptr, dL_dpsi2 ? L.H : nullptr);
   if (dL_dpsi1) {
-    hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
     hipLaunchKernelGGL(big_mul_kernel, dim3(big_nb256(N * M)), dim3(256), 0, s, N * M, dL_dpsi1, L.P, L.Lp);
     launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
   } else {
@@ -825,8 +837,10 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
   if (dL_dpsi2) {
     hipLaunchKernelGGL(symmetrise_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
-    if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2))) return st;
-    if ((st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1))) return st;
+    if (L.wide) st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
+    else if (!(st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2)))
+      st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
+    if (st) return st;
   }
   FinalizeArgs f{};
   f.M = M; f.Q = Q; f.QP = QP; f.Zc = L.zt.Zc; f.lam = L.zt.lam; f.variance = variance;

@@ -796,7 +796,7 @@ static rgp_status last_launch(rgp_handle h, const char* what) {
 extern "C" rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* variance, const double* inv_l,
                               double jitter, double* Kuu) {
   if (!h) return RGP_ERR_BAD_ARG;
-  rgp_status st = rgp_is_big(M) ? big_check(h, 1, M, Q) : check_geometry(h, 1, M, Q);
+  rgp_status st = (rgp_is_big(M) || rgp_qp(Q) > RGP_MAX_QP) ? big_check(h, 1, M, Q, true) : check_geometry(h, 1, M, Q);
   if (st) return st;
   LayerWs L;
   const size_t need = carve_layer(h, nullptr, 1, M, Q, 1, 1, L, nullptr);
@@ -841,7 +841,7 @@ extern "C" rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, con
                                       const double* Z, const double* variance, const double* inv_l, double* psi1,
                                       double* psi2) {
   if (!h) return RGP_ERR_BAD_ARG;
-  if (rgp_is_big(M)) return big_psi_forward(h, N, M, Q, mu, S, Z, variance, inv_l, psi1, psi2);
+  if (rgp_is_big(M) || rgp_qp(Q) > RGP_MAX_QP) return big_psi_forward(h, N, M, Q, mu, S, Z, variance, inv_l, psi1, psi2);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;
   LayerWs L;
@@ -914,7 +914,7 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
                                        double dL_dpsi0_sum, const double* dL_dpsi1, const double* dL_dpsi2, double* dvar,
                                        double* dinv_l, double* dZ, double* dmu, double* dS) {
   if (!h) return RGP_ERR_BAD_ARG;
-  if (rgp_is_big(M))
+  if (rgp_is_big(M) || rgp_qp(Q) > RGP_MAX_QP)
     return big_psi_backward(h, N, M, Q, mu, S, Z, variance, inv_l, dL_dpsi0_sum, dL_dpsi1, dL_dpsi2, dvar, dinv_l, dZ, dmu, dS);
   rgp_status st = check_geometry(h, N, M, Q);
   if (st) return st;

@@ -37,7 +37,8 @@ def make(N, M, Q, seed, nctrl=0):
 
 # (N, M, Q, control columns): one inducing block with idle lanes (129), exactly one full block (256), two blocks (300, 500),
 # three blocks (600); Q = 57 takes the one-column-per-wave forward kernel
-SHAPES = [(70, 129, 8, 2), (150, 256, 40, 20), (40, 300, 57, 3), (90, 500, 40, 20), (33, 600, 20, 0)]
+SHAPES = [(70, 129, 8, 2), (150, 256, 40, 20), (40, 300, 57, 3), (90, 500, 40, 20), (33, 600, 20, 0),
+          (60, 20, 80, 10), (45, 150, 130, 0)]      # windows wider than 64 columns (the pair-indexed GEMM forms), M below and above 128
 
 
 @pytest.mark.parametrize('N,M,Q,nctrl', SHAPES)

@@ -355,13 +355,14 @@ def test_unsupported_sizes_fail_loudly():
     m = DeepAutoreg([0, 3], Y, U=U, U_win=2, nDims=[1, 1], num_inducing=1025, inference_method='svi')   # M > 1024
     with pytest.raises(RgpError):
         m.evaluate()
-    # Q = 70 > 64 is fine for both bounds (tests/test_gpu_wide_windows.py); the unit entry points stop at 64
+    # Q = 70 > 64 is fine for both bounds and the unit entry points (tests/test_gpu_wide_windows.py, test_gpu_big.py); the entry
+    # point that cannot allocate stops at 64
     import torch
     from rgp_amd.capi import Handle
     hd = Handle()
     z = lambda *sh: torch.ones(*sh, dtype=torch.float64, device='cuda')
     with pytest.raises(RgpError):
-        hd.psi_forward(z(5, 70), z(5, 70), z(3, 70), z(1), z(70))
+        hd.psi_forward_static(z(5, 70), z(5, 70), z(3, 70), z(1), z(70), z(5, 3), z(3, 3))
     U3, Y3 = make_data(1, 1200, u_dim=1, y_dim=1)
     m3 = DeepAutoreg([0, 1030], Y3, U=U3, U_win=30, nDims=[1, 1], num_inducing=4, inference_method='svi')        # Q = 1060 > 1024
     with pytest.raises(RgpError):
