@@ -214,7 +214,7 @@ rgp_status rgp_matmul(rgp_handle h, int m, int n, int k, double alpha, const dou
  * the layer's posterior (woodbury_inv M x M, woodbury_vector M x D from rgp_layer_step) and the predictive mean/variance
  * become X[X_win+n] (variance clipped at 1e-15; <= 0 -> 1e-10, layers.py:1570).  X_dim == D.
  * Layouts: init_* [n_seq][X_win*D]; U_* [n_seq][u_rows][U_dim] (U_var NULL -> u_var_const); X_* [n_seq][X_win+steps][D].
- * Sizes: Q = X_win*D + U_win*U_dim <= 64 with M <= 1024, or Q <= 1024 with M <= 128 (RGP_ERR_BAD_ARG beyond). */
+ * Sizes: M <= 1024, Q = X_win*D + U_win*U_dim <= 1024 (RGP_ERR_BAD_ARG beyond). */
 rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_win, int U_win, int U_dim, int steps,
                        const double* Z, const double* variance, const double* inv_l, const double* woodbury_inv,
                        const double* woodbury_vector, const double* init_mean, const double* init_var,

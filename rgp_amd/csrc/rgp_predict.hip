@@ -272,14 +272,22 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_big_kernel(FreerunArgs a, 
   }
 }
 
-// Windows wider than 64 columns (any padded Q up to FRW_MAX_QP, M <= 128): the Gram terms of a step,
-// c[m,m'] = sum_q dml[q] z[m,q] z[m',q], no longer fit a register copy of z[m,:], so thread (m, part) keeps the FRW_MP
-// accumulators of its part of the m' sweep in registers and walks q once, reading z from the transposed copy ZcT[q][128]
-// (its own entry coalesced, the part's entries wave-uniform); the input row's terms are in dynamic LDS (4 x QP doubles).
-// Same arithmetic as freerun_kernel.
+// Windows wider than 64 columns (any padded Q up to FRW_MAX_QP, any M up to FRB_MAX_M): the Gram terms of a step,
+// c[m,m'] = sum_q dml[q] z[m,q] z[m',q], no longer fit a register copy of z[m,:].  The M x M pairs are visited in tiles of 128
+// inducing rows x 128 columns: thread (m, part) keeps the FRW_MP accumulators of its quarter of the tile's columns in registers
+// and walks q once per tile, reading z from a transposed copy ZT[q][Mld] (its own entry coalesced, the columns' entries
+// wave-uniform); the input row's terms are in dynamic LDS (4 x QP doubles).  Same arithmetic as freerun_kernel.
 #define FRW_MP 32
 #define FRW_MAX_QP 1024
-__global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a, const int QP, const double* __restrict__ ZcT,
+// ZT[q][m] = Zc[m][q], zero beyond M   (QP x Mld)
+__global__ void __launch_bounds__(256) frw_transpose_kernel(int M, int QP, int Mld, const double* __restrict__ Zc, double* __restrict__ ZT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= QP * Mld) return;
+  const int q = i / Mld, m = i % Mld;
+  ZT[i] = m < M ? Zc[(size_t)m * QP + q] : 0.0;
+}
+
+__global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a, const int QP, const int Mld, const double* __restrict__ ZT,
                                                                    const double* __restrict__ wv_g,
                                                                    const double* __restrict__ winv_g) {
   extern __shared__ double frw_rows[];
@@ -287,17 +295,13 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a,
   double* dmls = frw_rows + QP;
   double* e1s = frw_rows + 2 * QP;
   double* mus = frw_rows + 3 * QP;
-  __shared__ double hbuf[RGP_PSI2_TEAM], p1buf[RGP_PSI2_TEAM];
+  __shared__ double hbuf[FRB_MAX_M], p1buf[FRB_MAX_M];
   __shared__ double red[8][FR_DC + 2];
   __shared__ double scratch[16];
   const int M = a.M, Q = a.Q, D = a.D;
   const int t = threadIdx.x, tr = t & (RGP_PSI2_TEAM - 1);
-  const int part = __builtin_amdgcn_readfirstlane(t >> 7);            // 4 parts
-  const bool act = tr < M;
-  const int tm = act ? tr : M - 1;
+  const int part = __builtin_amdgcn_readfirstlane(t >> 7);            // 4 parts of 32 columns
   const int seq = blockIdx.x;
-  const int Mq = (M + 3) / 4;
-  const int mp0 = part * Mq, mp1 = (mp0 + Mq < M) ? mp0 + Mq : M;
   const int Qx = a.X_win * a.X_dim;
   const int64_t T_out = a.X_win + a.steps;
   double* Xm = a.X_mean + (size_t)seq * T_out * a.X_dim;
@@ -309,11 +313,6 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a,
   for (int i = t; i < Qx; i += FR_THREADS) {
     Xm[i] = a.init_mean ? a.init_mean[(size_t)seq * Qx + i] : 0.0;
     Xv[i] = a.init_var ? a.init_var[(size_t)seq * Qx + i] : 1.0;
-  }
-  double ellq = 0.0;
-  for (int q = 0; q < QP; ++q) {
-    const double z = ZcT[(size_t)q * RGP_PSI2_TEAM + tm];
-    ellq += 0.25 * a.lam[q] * z * z;
   }
   __syncthreads();
 
@@ -337,55 +336,72 @@ __global__ void __launch_bounds__(FR_THREADS) freerun_wide_kernel(FreerunArgs a,
     sl2 = block_sum(sl2, scratch); sl1 = block_sum(sl1, scratch); sdm = block_sum(sdm, scratch);
     const double g0 = 2.0 * logvar - 0.5 * sl2 - sdm, g1 = logvar - 0.5 * sl1;
     __syncthreads();
-    // ---- one walk over q: h, the psi1 exponent and the Gram terms of this thread's part of the sweep ----
-    double c[FRW_MP];
-#pragma unroll
-    for (int j = 0; j < FRW_MP; ++j) c[j] = 0.0;
-    double h = 0.0, e = 0.0;
-    for (int q = 0; q < QP; ++q) {
-      const double z = ZcT[(size_t)q * RGP_PSI2_TEAM + tm];
-      const double* __restrict__ zr = ZcT + (size_t)q * RGP_PSI2_TEAM + mp0;        // wave-uniform
-      const double aq = z * dmls[q];
-      h += z * d2s[q] * (mus[q] - 0.25 * z);
-      const double df = mus[q] - z;
-      e += e1s[q] * df * df;
-#pragma unroll
-      for (int j = 0; j < FRW_MP; ++j) c[j] += aq * zr[j];
+    // ---- per inducing row: h, psi1 ----
+    for (int m = t; m < M; m += FR_THREADS) {
+      double h = 0.0, e = 0.0;
+      for (int q = 0; q < QP; ++q) {
+        const double z = ZT[(size_t)q * Mld + m];
+        h += z * d2s[q] * (mus[q] - 0.25 * z) - 0.25 * a.lam[q] * z * z;
+        const double df = mus[q] - z;
+        e += e1s[q] * df * df;
+      }
+      hbuf[m] = h;
+      p1buf[m] = exp(g1 - 0.5 * e);
     }
-    h -= ellq;
-    const double p1 = exp(g1 - 0.5 * e);
-    if (part == 0) { hbuf[tr] = h; p1buf[tr] = act ? p1 : 0.0; }
-    const double base = act ? (g0 + h) : -INFINITY;
     __syncthreads();
-    // ---- sweep over m' (repeated per chunk of FR_DC outputs) ----
+    // ---- the pairs, tile by tile (repeated per chunk of FR_DC outputs) ----
     for (int d0 = 0; d0 < D; d0 += FR_DC) {
       const int dc = (D - d0 < FR_DC) ? D - d0 : FR_DC;
-      double wvm[FR_DC], acc[FR_DC];
+      double acc[FR_DC];
 #pragma unroll
-      for (int d = 0; d < FR_DC; ++d) { wvm[d] = (d < dc) ? wv_g[(size_t)tm * D + d0 + d] : 0.0; acc[d] = 0.0; }
+      for (int d = 0; d < FR_DC; ++d) acc[d] = 0.0;
       double trc = 0.0;
+      for (int mb = 0; mb < M; mb += RGP_PSI2_TEAM) {
+        const int m = mb + tr;
+        const bool act = m < M;
+        const int tm = act ? m : M - 1;
+        double wvm[FR_DC];
 #pragma unroll
-      for (int j = 0; j < FRW_MP; ++j) {
-        const int mp = mp0 + j;
-        if (mp < mp1) {
-          const double* __restrict__ ws = wv_g + (size_t)mp * D + d0;
-          const double p = exp((base + hbuf[mp]) - 0.5 * c[j]);
-          const double tt = p - (act ? p1 : 0.0) * p1buf[mp];
-          trc += winv_g[(size_t)mp * M + tm] * p;
+        for (int d = 0; d < FR_DC; ++d) wvm[d] = (d < dc) ? wv_g[(size_t)tm * D + d0 + d] : 0.0;
+        const double base = act ? (g0 + hbuf[tm]) : -INFINITY;
+        const double p1 = act ? p1buf[tm] : 0.0;
+        for (int cb = 0; cb < M; cb += RGP_PSI2_TEAM) {
+          const int mp0 = cb + part * FRW_MP;                          // wave-uniform
+          double c[FRW_MP];
 #pragma unroll
-          for (int d = 0; d < FR_DC; ++d)
-            if (d < dc) acc[d] += tt * wvm[d] * ws[d];
+          for (int j = 0; j < FRW_MP; ++j) c[j] = 0.0;
+          if (mp0 < M) {
+            for (int q = 0; q < QP; ++q) {
+              const double aq = ZT[(size_t)q * Mld + tm] * dmls[q];
+              const double* __restrict__ zr = ZT + (size_t)q * Mld + mp0;
+#pragma unroll
+              for (int j = 0; j < FRW_MP; ++j) c[j] += aq * zr[j];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < FRW_MP; ++j) {
+            const int mp = mp0 + j;
+            if (mp < M) {
+              const double* __restrict__ ws = wv_g + (size_t)mp * D + d0;
+              const double p = exp((base + hbuf[mp]) - 0.5 * c[j]);
+              const double tt = p - p1 * p1buf[mp];
+              trc += winv_g[(size_t)mp * M + tm] * p;
+#pragma unroll
+              for (int d = 0; d < FR_DC; ++d)
+                if (d < dc) acc[d] += tt * wvm[d] * ws[d];
+            }
+          }
         }
       }
       const int wave = t >> 6, lane = t & 63;
 #pragma unroll
       for (int d = 0; d < FR_DC; ++d) {
-        const double s = wave_sum(acc[d]);
-        if (lane == 0) red[wave][d] = s;
+        const double sv = wave_sum(acc[d]);
+        if (lane == 0) red[wave][d] = sv;
       }
       {
-        const double s = wave_sum(trc);
-        if (lane == 0) red[wave][FR_DC] = s;
+        const double sv = wave_sum(trc);
+        if (lane == 0) red[wave][FR_DC] = sv;
       }
       __syncthreads();
       if (t < dc) {
@@ -422,21 +438,23 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   const int X_dim = D;
   const int Q = X_win * X_dim + U_win * U_dim;
   const bool wide = rgp_qp(Q) > RGP_MAX_QP;
-  if (M > FRB_MAX_M || Q <= 0 || (wide && (M > RGP_MAX_M || rgp_qp(Q) > FRW_MAX_QP)))
-    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 1024 and 0 < Q <= 64, or M <= 128 and Q <= 1024, in this build");
+  if (M > FRB_MAX_M || Q <= 0 || rgp_qp(Q) > FRW_MAX_QP)
+    return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: needs M <= 1024 and 0 < Q <= 1024 in this build");
   const bool big = M > RGP_MAX_M;
   if (U_win > 0 && (!U_mean || u_rows - u_skip < steps + U_win - 1))
     return rgp_fail(h, RGP_ERR_BAD_ARG, "rgp_freerun: not enough input rows for the requested steps");
   const int QP = rgp_qp(Q);
   // Z-derived terms in the handle's workspace
   rgp_status st;
-  const size_t need = ((size_t)2 * QP + (size_t)M * QP + (size_t)QP * RGP_PSI2_TEAM + 2 * (size_t)M * M + 2) * sizeof(double) + 9 * 256;
+  const int Mld = (M + RGP_PSI2_TEAM - 1) / RGP_PSI2_TEAM * RGP_PSI2_TEAM;
+  const size_t need = ((size_t)2 * QP + (size_t)M * QP + (size_t)QP * RGP_PSI2_TEAM + 2 * (size_t)M * M + 2 + (wide ? (size_t)QP * Mld : 0)) * sizeof(double) + 10 * 256;
   if ((st = rgp_ensure_ws(h, need))) return st;
   WsAlloc ws(h->ws);
   ZTerms zt{};
   zt.M = M; zt.Q = Q; zt.QP = QP;
   zt.c = ws.take<double>(QP); zt.lam = ws.take<double>(QP); zt.Zc = ws.take<double>((size_t)M * QP);
   zt.ZcT = ws.take<double>((size_t)QP * RGP_PSI2_TEAM); zt.zd = ws.take<double>((size_t)M * M); zt.Kuu = ws.take<double>((size_t)M * M);
+  double* ZT = wide ? ws.take<double>((size_t)QP * Mld) : nullptr;
   launch_prep_z(h->stream, M, Q, QP, Z, variance, inv_l, RGP_JITTER, zt);
   FreerunArgs a{};
   a.n_seq = n_seq; a.M = M; a.Q = Q; a.D = D; a.X_win = X_win; a.X_dim = X_dim; a.U_win = U_win; a.U_dim = U_dim; a.steps = steps;
@@ -444,8 +462,9 @@ extern "C" rgp_status rgp_freerun(rgp_handle h, int n_seq, int M, int D, int X_w
   a.wv = woodbury_vector; a.init_mean = init_mean; a.init_var = init_var; a.U_mean = U_mean; a.U_var = U_var;
   a.u_var_const = u_var_const; a.X_mean = X_mean; a.X_var = X_var;
   if (wide) {
-    hipLaunchKernelGGL(freerun_wide_kernel, dim3(n_seq), dim3(FR_THREADS), 4 * (size_t)QP * sizeof(double), h->stream, a, QP,
-                       zt.ZcT, a.wv, a.winv);
+    hipLaunchKernelGGL(frw_transpose_kernel, dim3((QP * Mld + 255) / 256), dim3(256), 0, h->stream, M, QP, Mld, zt.Zc, ZT);
+    hipLaunchKernelGGL(freerun_wide_kernel, dim3(n_seq), dim3(FR_THREADS), 4 * (size_t)QP * sizeof(double), h->stream, a, QP, Mld,
+                       ZT, a.wv, a.winv);
   } else if (big) {
     switch (QP) {
 #define FRB(qp) case qp: freerun_big_launch<qp>(h->stream, a); break;

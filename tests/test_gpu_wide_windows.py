@@ -34,18 +34,21 @@ def test_wide_window_svi_steps_run():
 @pytest.mark.parametrize('cfg', [
     dict(wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=12, U_win=40, u_dim=1, y_dim=2),       # Q = 80 / 120 / 80
     dict(wins=(0, 20, 20), nDims=(16, 16, 16), n_seq=1, T=45, M=100, U_win=20, u_dim=1, y_dim=16),  # Q = 340 / 640 / 320, D = 16
+    dict(wins=(0, 40, 40), nDims=(2, 2, 1), n_seq=2, T=70, M=150, U_win=40, u_dim=1, y_dim=2),      # two tiles of inducing rows
+    dict(wins=(0, 30, 4), nDims=(2, 2, 1), n_seq=2, T=50, M=260, U_win=4, u_dim=1, y_dim=2),        # three tiles; Q = 8 / 66 / 30
 ])
 def test_wide_window_freerun_matches_oracle(cfg):
     """Moment-matching free-run through layers with wide windows (layers.py:1537-1571): the generic-Q kernel vs the oracle."""
     import numpy as np
     o, g = build_pair(fast_psi=True, chunk=8, **cfg)
-    compare(o, g)                                  # also fills the posteriors
+    compare(o, g, rtol=1e-9 if cfg['M'] <= 128 else 1e-6)      # also fills the posteriors
     U = np.random.default_rng(9).standard_normal((cfg['U_win'] + 25, cfg['u_dim']))
     want, got = o.freerun(U), g.freerun(U)
     g.handle.sync()
+    loose = cfg['M'] > 128        # hundreds of inducing points in a few input dimensions: cond(K_uu) is at the jitter's limit
     for (wm, wv), (gm, gv) in zip(want, got):
-        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-8, atol=1e-10)
-        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-7 if loose else 1e-8, atol=1e-9 if loose else 1e-10)
+        np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-6 if loose else 1e-7, atol=1e-10 if loose else 1e-12)
 
 
 @pytest.mark.parametrize('cfg', [
