@@ -187,8 +187,9 @@ static int64_t big_workspace_bytes(int64_t N, int M, int Q, int D) {
   rgp_ctx tmp;
   BigWs L;
   SviChain ch{}; ch.M = M; ch.D = D > 0 ? D : 1;
+  VarDtcChain vc{}; vc.M = M; vc.D = D > 0 ? D : 1;
   const BigPlan p = big_plan(&tmp, N, M, Q);
-  return (int64_t)big_carve(nullptr, p, N, M, Q, D, 4096, L, &ch);
+  return (int64_t)big_carve(nullptr, p, N, M, Q, D, 4096, L, &ch, &vc);       // both bounds' buffers: an upper bound for either
 }
 
 static inline unsigned big_nb256(int64_t n) { return (unsigned)((n + 255) / 256); }

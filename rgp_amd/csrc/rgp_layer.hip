@@ -772,7 +772,7 @@ extern "C" int64_t rgp_workspace_bytes(int64_t N, int M, int Q, int D) {
 }
 
 static inline bool rgp_is_big(int M) { return M > RGP_MAX_M; }
-// windows wider than 64 columns (SVI layer step only): the GEMM-shaped path of rgp_wideq_impl.h
+// windows wider than 64 columns: the GEMM-shaped path of rgp_wideq_impl.h
 static inline bool rgp_is_wide(const rgp_layer_in* in) { return rgp_qp(in->X_win * in->X_dim + in->U_win * in->U_dim) > RGP_MAX_QP; }
 
 static rgp_status check_geometry(rgp_handle h, int64_t N, int M, int Q) {
