@@ -1,5 +1,6 @@
-// rgp_wideq_impl.h -- SVI layer step for windows wider than 64 columns (64 < padded Q <= 1024, any M <= 1024).  Included by
-// rgp_layer.hip after rgp_big_impl.h; entered from big_svi_layer_step.
+// rgp_wideq_impl.h -- the psi statistics and their gradients for windows wider than 64 columns (64 < padded Q <= 1024, any
+// M <= 1024).  Included by rgp_big_impl.h; entered from the blocked layer steps of both bounds (big_svi_layer_step,
+// big_vardtc_layer_step) and from the unit entry points (big_psi_forward / big_psi_backward).
 //
 // With Q in the hundreds the per-thread arrays of the sweep kernels (dzl[Q], y[Q]) cannot stay in registers, and the two
 // O(N M^2 Q) contractions of the psi2 term become what they are algebraically: batched matrix products with the data rows as
@@ -12,8 +13,10 @@
 // and, once per layer step, from v alone:  [a1 | vz2 | w] = V [Z | Z^2 | 1],  B1 = V^T (d2 o mu),  B2 = V^T d2, so that
 //   a23 = (vz2 + T) / 2,  row gradients as in the sweep kernels' epilogue,  dZ2 = 2 B1 - Z o B2 - dZ3.
 // (psi2 exponent and its gradients: GPy's rbf_psi_comp closed forms as restated in rgp_psi.hip; bound algebra:
-// autoreg/inference/svi_vardtc.py:70-195.)  psi1 and h come from a generic-Q kernel; everything else of the step is the
-// blocked path's (GEMM-shaped psi1 side, chain by M, finalisation, window scatter).
+// autoreg/inference/svi_vardtc.py:70-195, vardtc.py:88-208.)  psi1 and h are four N x M x Q products (wq_psi1_fwd); everything
+// else of a step is the blocked path's (GEMM-shaped psi1 backward side, chain by M, finalisation, window scatter).  The N x P
+// weights are held for X.nc data rows at a time; the collapsed bound, whose dL/dpsi2 needs psi2 first, runs the Gram product
+// and a forward-only exponential pass before the chain (wq_psi2_forward) and everything again after it (wq_psi2).
 #pragma once
 
 
