@@ -468,6 +468,11 @@ class DeepAutoreg(object):
     # ------------------------------------------------------------------------------------------------------------
     def _index_set(self, seqs=None):
         """Indices of param_array that belong to the globals and to the latents of ``seqs``."""
+        if seqs is None:                      # every L-BFGS evaluation asks for this one: built (and copied to the device) once
+            cached = getattr(self, '_index_all', None)
+            if cached is None:
+                cached = self._index_all = self._index_set(range(self.nSeq))
+            return cached
         idx = [np.arange(self.n_global)]
         ss = range(self.nSeq) if seqs is None else seqs
         for s in ss:
