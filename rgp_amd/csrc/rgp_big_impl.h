@@ -137,6 +137,7 @@ struct BigWs {
   double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
   int64_t *row_off, *own_pre, *up_pre;
   double *r2, *T2, *PsiR_part, *PsiR, *dYvar_row;     // collapsed bound only
+  double* fp2_part; int frs;                            // psi2 forward on the matrix pipe: partial sums per row split, row splits
 };
 
 static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, int D, int n_seq, BigWs& L, SviChain* ch,
@@ -175,6 +176,13 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
   L.wide = QP > RGP_MAX_QP;
   if (L.wide) wq_carve(ws, p, N, M, L.wq);
+  {
+    const int nb = (M + 31) / 32, blocks = nb * (nb + 1) / 2;      // 32 x 32 pair blocks of the matrix-pipe forward kernel
+    int64_t rs = (1536 + blocks - 1) / blocks;
+    if (rs > (N + 63) / 64) rs = (N + 63) / 64;
+    L.frs = (int)(rs < 1 ? 1 : rs);
+    L.fp2_part = ws.take<double>((size_t)L.frs * mm);
+  }
   if (vc) {
     vardtc_chain_carve(*vc, ws);
     L.r2 = ws.take<double>(N); L.T2 = ws.take<double>(nm); L.dYvar_row = ws.take<double>(N);
@@ -760,6 +768,132 @@ static void launch_big_psi1_bwd(hipStream_t s, const BigPlan& p, int64_t N, int 
   launch_reduce_batch(s, 2, segs);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// psi2 forward sum on the matrix pipe, over the unordered pairs (a <= b) of inducing rows (psi2 is symmetric):
+//   psi2[a,b] = sum_n exp(g0[n] + h[n,a] + h[n,b] + sum_q dm[n,q] z[a,q] z[b,q])
+// Workgroup = a 32 x 32 block of (a, b) with block(b) >= block(a), times a range of data rows.  Only the 64 inducing rows of
+// the block are touched, so per block of 64 data rows the operands in LDS are small (dm rows, g0, 2 x 32 columns of h) against
+// 64 x 1024 exponents.  A wave owns 8 sub-tiles of 16 pairs (one a, 16 consecutive b); for a sub-tile the products
+// z[a,q] z[b,q] are the B operand of v_mfma_f64_16x16x4 (built once per row block from the z rows in LDS), the A operand is the
+// dm tile, and QP / 4 matrix instructions turn 16 rows x 16 pairs into exponents.  The exponentials (table form) and the sums
+// over the rows stay in the lane (row = (lane >> 4) + 4 r, b = lane & 15).  Partial sums per (row split, a, b) are summed in
+// fixed order and mirrored by bfm_finish_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+#define BFM_R 64            // data rows per block
+#define BFM_B 32            // inducing rows per side of a pair block
+template <int KS>
+__global__ void __launch_bounds__(512, 2) big_psi2_fwd_mfma_kernel(const int64_t N, const int M, const double* __restrict__ Zc,
+                                                                    const double* __restrict__ dm, const double* __restrict__ H,
+                                                                    const double* __restrict__ g0, double* __restrict__ part) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int QP = 4 * KS, LD = QP + 1, HLD = BFM_B + 1;
+  __shared__ double etab[PSI2_EXP_TAB];
+  __shared__ double Za[BFM_B * LD], Zb[BFM_B * LD];
+  __shared__ double dmL[BFM_R * LD];
+  __shared__ double g0L[BFM_R];
+  __shared__ double HA[BFM_R * HLD], HB[BFM_R * HLD];
+  const int ab = blockIdx.x, bb = blockIdx.y;
+  if (bb < ab) return;                                 // the lower blocks mirror the upper ones
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, c = lane & 15;
+  const int a0 = ab * BFM_B, b0 = bb * BFM_B;
+  if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
+  for (int i = t; i < BFM_B * QP; i += 512) {
+    const int r = i / QP, q = i - r * QP;
+    Za[r * LD + q] = (a0 + r < M) ? Zc[(size_t)(a0 + r) * QP + q] : 0.0;
+    Zb[r * LD + q] = (b0 + r < M) ? Zc[(size_t)(b0 + r) * QP + q] : 0.0;
+  }
+  const int64_t per = ((N + gridDim.z - 1) / gridDim.z + BFM_R - 1) / BFM_R * BFM_R;
+  const int64_t r0 = (int64_t)blockIdx.z * per;
+  const int64_t r1 = (r0 + per < N) ? r0 + per : N;
+  double psum[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) psum[u] = 0.0;
+  for (int64_t rb = r0; rb < r1; rb += BFM_R) {
+    __syncthreads();                                   // the previous block's operand reads are done (first pass: Za, Zb, etab written)
+    for (int i = t; i < BFM_R * QP; i += 512) {
+      const int rr = i / QP, q = i - rr * QP;
+      dmL[rr * LD + q] = (rb + rr < r1) ? dm[(size_t)(rb + rr) * QP + q] : 0.0;
+    }
+    for (int i = t; i < BFM_R * BFM_B; i += 512) {
+      const int rr = i >> 5, jx = i & 31;
+      const bool in = rb + rr < r1;
+      HA[rr * HLD + jx] = (in && a0 + jx < M) ? H[(size_t)(rb + rr) * M + a0 + jx] : 0.0;
+      HB[rr * HLD + jx] = (in && b0 + jx < M) ? H[(size_t)(rb + rr) * M + b0 + jx] : 0.0;
+    }
+    if (t < BFM_R) g0L[t] = (rb + t < r1) ? g0[rb + t] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                      // the wave's sub-tiles: a = a0 + 4 wave + (u >> 1), b = b0 + 16 (u & 1) + c
+      asm volatile("" ::: "memory");                   // keep each sub-tile's operand reads with its own instructions
+      const int al = 4 * wave + (u >> 1), bl = 16 * (u & 1) + c;
+      const bool valid = (a0 + al < M) && (b0 + bl < M) && (a0 + al <= b0 + bl);
+      double zb[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) zb[k] = Za[al * LD + 4 * k + g] * Zb[bl * LD + 4 * k + g];
+#pragma unroll
+      for (int rs = 0; rs < BFM_R / 16; ++rs) {
+        asm volatile("" ::: "memory");
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dmL[(rs * 16 + c) * LD + 4 * k + g], zb[k], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = rs * 16 + g + 4 * r;
+          const double e = exp_tab(acc[r] + g0L[nl] + HA[nl * HLD + al] + HB[nl * HLD + bl], etab);
+          psum[u] += (valid && rb + nl < r1) ? e : 0.0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    double v = psum[u];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const int al = 4 * wave + (u >> 1), bl = 16 * (u & 1) + c;
+    if (g == 0 && a0 + al < M && b0 + bl < M && a0 + al <= b0 + bl)
+      part[(size_t)blockIdx.z * M * M + (size_t)(a0 + al) * M + (b0 + bl)] = v;
+  }
+}
+
+// psi2[a,b] = psi2[b,a] = sum over the row splits of part[split][a,b]   (a <= b; fixed order)
+__global__ void __launch_bounds__(256) bfm_finish_kernel(const int M, const int nsplit, const double* __restrict__ part, double* __restrict__ psi2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * M) return;
+  const int a = i / M, b = i % M;
+  if (b < a) return;
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * M * M + i];
+  psi2[i] = s;
+  psi2[(size_t)b * M + a] = s;
+}
+
+static rgp_status launch_big_psi2_fwd_mfma(rgp_handle h, hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt,
+                                           const double* dm, const double* H, double* part, int rsplit, double* psi2) {
+  const int nb = (M + BFM_B - 1) / BFM_B;
+  const dim3 grid((unsigned)nb, (unsigned)nb, (unsigned)rsplit);
+  switch (zt.QP) {
+#define BFM(qp) case qp: hipLaunchKernelGGL((big_psi2_fwd_mfma_kernel<qp / 4>), grid, dim3(512), 0, s, N, M, zt.Zc, dm, H, rt.g0, part); break;
+    BFM(8) BFM(16) BFM(20) BFM(24) BFM(32) BFM(40) BFM(48) BFM(56) BFM(64)
+#undef BFM
+    default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 forward (blocked): unsupported padded Q");
+  }
+  hipLaunchKernelGGL(bfm_finish_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, rsplit, part, psi2);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 forward (matrix pipe): ") + hipGetErrorString(e));
+  return RGP_OK;
+}
+
+// psi2 forward sum of the blocked path: the register-accumulator VALU kernel over the column groups that reach the diagonal
+// (default), or the matrix-pipe kernel over 32 x 32 blocks of unordered pairs (RGP_PSI2_FWD_MFMA=1, read per call).  Both visit
+// about the same number of (row, pair) elements and fp64 MFMA has the VALU's multiply-add rate on this chip, so they take the
+// same time (243 against 255 ms per Q = 40 launch at M = 500, N = 524 128); the VALU kernel stays the default.
+static rgp_status big_psi2_forward(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, BigWs& L, double* psi2) {
+  if (getenv("RGP_PSI2_FWD_MFMA") == nullptr) return launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, psi2);
+  return launch_big_psi2_fwd_mfma(h, s, N, M, L.zt, L.rt, L.dm, L.H, L.fp2_part, L.frs, psi2);
+}
+
 static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok = false) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
   if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
@@ -800,7 +934,7 @@ static rgp_status big_psi_forward(rgp_handle h, int64_t N, int M, int Q, const d
   launch_big_psi1_fwd(s, N, M, L.zt, L.rt, psi1, psi2 ? L.H : nullptr);
   if (psi2) {
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * p.QP)), dim3(256), 0, s, N * p.QP, p.QP, L.rt.d2, L.zt.lam, L.dm);
-    if ((st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, psi2))) return st;
+    if ((st = big_psi2_forward(h, s, p, N, M, L, psi2))) return st;
   }
   return last_launch(h, "rgp_psi_forward (blocked)");
 }
@@ -839,7 +973,7 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
     hipLaunchKernelGGL(symmetrise_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
     if (L.wide) st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
-    else if (!(st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2)))
+    else if (!(st = big_psi2_forward(h, s, p, N, M, L, L.psi2)))
       st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
     if (st) return st;
   }
@@ -938,7 +1072,7 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
     st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
     prof_end(h);
   } else {
-    st = launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
+    st = big_psi2_forward(h, s, p, N, M, L, L.psi2);
     if (!st) st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1, true);
   }
   if (st) return st;
@@ -1074,7 +1208,7 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
     if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)M * M, (int64_t)M * M, L.PsiR_part, L.PsiR, 1.0, 0);
   }
   st = L.wide ? wq_psi2_forward(h, s, p, N, M, L, L.wq)
-              : launch_big_psi2_fwd(h, s, p, N, M, L.zt, L.rt, L.dm, L.H, L.p2_part, L.psi2);
+              : big_psi2_forward(h, s, p, N, M, L, L.psi2);
   if (st) return st;
   }
   if (phase == 1) {                                  // hand the local statistics to the caller (vardtc.py:65-67 stub)

@@ -209,3 +209,21 @@ def test_big_freerun_matches_oracle(M, inference):
     for (wm, wv), (gm, gv) in zip(want, got):
         np.testing.assert_allclose(gm[0].cpu().numpy(), wm, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(gv[0].cpu().numpy(), wv, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize('N,M,Q,nctrl', [(150, 256, 40, 20), (90, 500, 40, 20), (33, 600, 20, 0), (40, 300, 57, 3)])
+def test_big_psi2_forward_on_the_matrix_pipe(H, monkeypatch, N, M, Q, nctrl):
+    """The alternative psi2 forward kernel (v_mfma_f64_16x16x4 over 32 x 32 blocks of unordered pairs, RGP_PSI2_FWD_MFMA=1)
+    against the oracle and against the default kernel."""
+    from oracle import psi_stats as ps
+    mu, S, Z, var, il = make(N, M, Q, 31 + N, nctrl)
+    args = (dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il))
+    _, p2_default = H.psi_forward(*args)
+    H.sync()
+    monkeypatch.setenv('RGP_PSI2_FWD_MFMA', '1')
+    _, p2 = H.psi_forward(*args)
+    H.sync()
+    ref2 = ps.PsiStatsFast(16).psi2(var, il, Z, mu, S)
+    assert rel(p2.cpu().numpy(), ref2) < 1e-11
+    assert rel(p2.cpu().numpy(), p2_default.cpu().numpy()) < 1e-12
+    assert np.array_equal(p2.cpu().numpy(), p2.cpu().numpy().T)
