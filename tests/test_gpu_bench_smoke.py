@@ -48,3 +48,14 @@ def test_two_process_path_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['value'] > 0
+
+
+def test_wide_window_line():
+    """--wide: config 4 read with 16-dimensional hidden layers (windows of 340 / 640 / 320 columns), at a tiny size."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--wide', '--T', '96', '--n-total', '4', '--minibatch', '2',
+                        '--steps', '2', '--warmup', '1'], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 1 and j['value'] > 0 and j['roofline']['bound'] == 'mfma' and j['roofline']['launches'] == 6
+    assert 'config4-wide' in j['config']['workload']
+    assert j['elbo_rel_err_vs_oracle'] < 1e-10
