@@ -105,8 +105,20 @@ static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q)
   Q.nc = nc;
   const int64_t nexp = (nc + Q.rb - 1) / Q.rb;
   const int tiles = ((P + 127) / 128) * ((p.QP + 127) / 128);  // 128 x 128 output tiles of the row-split product C
-  Q.nsplit = (2048 + tiles - 1) / tiles;
-  if (Q.nsplit > 16) Q.nsplit = 16;
+  // row splits of C: 1024 to 3072 workgroups of equal length, the count that leaves the fewest of the chip's 512 workgroup
+  // slots (256 CUs x 2) idle in the last round
+  Q.nsplit = 1;
+  if (tiles < 2048) {
+    double best = 0.0;
+    int lo = (1024 + tiles - 1) / tiles, hi = (3072 + tiles - 1) / tiles;
+    if (lo > 32) lo = 32;
+    if (hi > 32) hi = 32;
+    for (int ns = lo; ns <= hi; ++ns) {
+      const int w = tiles * ns;
+      const double fill = (double)w / (512.0 * ((w + 511) / 512));
+      if (fill > best + 1e-9) { best = fill; Q.nsplit = ns; }
+    }
+  }
   Q.E = ws.take<double>((size_t)nc * P);
   Q.ZZ2 = ws.take<double>((size_t)p.QP * P);
   Q.vrow = ws.take<double>((size_t)N * M);

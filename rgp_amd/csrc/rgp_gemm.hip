@@ -103,9 +103,10 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Large products (both output dimensions in the hundreds or more): block tile 128 x 128, every wave a 64 x 64 sub-tile =
-// 4 x 4 MFMA tiles (16 accumulators, 8 operand reads per 16 MFMAs), which halves the operand bytes a workgroup pulls through
-// L2 per flop.  Tiles are handed out so that the workgroups resident on one XCD (linear workgroup ids that are equal
+// Large products (both output dimensions in the hundreds or more): block tile 128 x 128 over eight waves, every wave a
+// 64 x 32 sub-tile = 4 x 2 MFMA tiles (8 accumulators, 6 operand reads per 8 MFMAs, 120 VGPRs, so that two workgroups =
+// four waves per SIMD fit); the larger block tile halves the operand bytes a workgroup pulls through L2 per flop against
+// the 64 x 64 kernel above.  Tiles are handed out so that the workgroups resident on one XCD (linear workgroup ids that are equal
 // modulo 8) work on an 8 x 8 patch of neighbouring tiles and share its 16 operand strips in that XCD's L2.
 // ------------------------------------------------------------------------------------------------------------------
 #define GL_M 128
