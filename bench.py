@@ -237,8 +237,8 @@ def main():
                          'avg_launch_ms': psi2_ms / max(psi2_n, 1), 'launches': psi2_n,
                          'algorithmic_flop_per_launch': flops / max(psi2_n, 1),
                          'note': ('flop = 3*N*M*(M+1)*Q per psi2 term as executed: three N x P x Q products over the P = M(M+1)/2 pairs of '
-                                  'inducing rows (the dense factorised form counts 4*N*M*M*Q); measured fp64 MFMA ceiling of this chip: '
-                                  '49 TFLOP/s (profiles/r1_f64_peak.txt)') if a.wide else
+                                  'inducing rows (the dense factorised form counts 4*N*M*M*Q); each product alone runs at about 50 TFLOP/s '
+                                  '(profiles/r2_wide_kernel_stats.csv)') if a.wide else
                                  ('flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
                                   'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q')},
         }
