@@ -73,6 +73,11 @@ class Handle(object):
         """Fixed summation order in the psi2 pass (bit-reproducible, slower); include/rgp_hip.h rgp_set_deterministic."""
         self._check(self.lib.rgp_set_deterministic(self.h, 1 if on else 0))
 
+    def set_psi2_pair(self, mode):
+        """Kernels of the fused psi2 pass: 0 sweep (vector pipe), 1 pair form where it pays, 2 pair form wherever it fits,
+        -1 the RGP_PSI2_PAIR environment variable or 1; include/rgp_hip.h rgp_set_psi2_pair."""
+        self._check(self.lib.rgp_set_psi2_pair(self.h, int(mode)))
+
     def side_streams_independent(self):
         """How many of the library's three side streams run next to the main stream (include/rgp_hip.h)."""
         return int(self.lib.rgp_side_streams_independent(self.h))

@@ -78,6 +78,7 @@ struct rgp_ctx {
   bool prepared_rows[NSLOT] = {};     // FIFO entry also has its window tables / row terms (false: chain-only prepare)
   bool overlap = true;
   bool deterministic = false;       // rgp_set_deterministic: fixed-order psi2 kernels only
+  int psi2_pair = -1;               // rgp_set_psi2_pair: 0 sweep kernels, 1 pair form where it pays, 2 wherever it fits; -1: RGP_PSI2_PAIR or 1
   hipStream_t side_pre = nullptr, side_post = nullptr, side_rows = nullptr;
   hipEvent_t ev_prep = nullptr, ev_stats = nullptr;
   hipEvent_t ev_pre[NSLOT] = {};

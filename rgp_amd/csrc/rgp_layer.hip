@@ -219,6 +219,12 @@ extern "C" rgp_status rgp_set_deterministic(rgp_handle h, int on) {
   return RGP_OK;
 }
 
+extern "C" rgp_status rgp_set_psi2_pair(rgp_handle h, int mode) {
+  if (!h || mode < -1 || mode > 2) return RGP_ERR_BAD_ARG;
+  h->psi2_pair = mode;
+  return RGP_OK;
+}
+
 extern "C" rgp_status rgp_set_profiling(rgp_handle h, int on) {
   if (!h) return RGP_ERR_BAD_ARG;
   h->profiling = on != 0;
@@ -714,6 +720,7 @@ struct LayerWs {
   double *dz1_part, *dz1, *dz2_part, *dz2, *dlam1_part, *dlam1, *dlam2_part, *dlam2, *lsum1_part, *lsum1, *wsum2_part, *wsum2;
   double *yry_part, *yry, *psi1Y_part, *psi1Y, *psi0sum, *psi0coef, *elbo_part, *fin_dlrow, *fin_gsum;
   double *r2, *dYvar_row, *PsiR_part, *PsiR;      // collapsed bound only
+  double *pair_ws;                                // pair-form psi2 pass (nullptr when the handle's mode does not select it)
   int64_t *row_off, *own_pre, *up_pre;
   int nblk1, nblk2;
 };
@@ -758,6 +765,10 @@ static size_t carve_layer(rgp_handle h, char* base, int64_t N, int M, int Q, int
     L.r2 = ws.take<double>(N); L.dYvar_row = ws.take<double>(N);
     L.PsiR_part = ws.take<double>((size_t)L.nblk1 * M * M); L.PsiR = ws.take<double>((size_t)M * M);
     vardtc_chain_carve(*vc, ws);
+  }
+  {                                               // last: nothing in front of it moves when the mode changes
+    PairGeom pg;
+    L.pair_ws = (!vc && psi2_pair_selected(h, N, M, QP, pg)) ? ws.take<double>(psi2_pair_ws_doubles(pg, N)) : nullptr;
   }
   return ws.off;
 }
@@ -941,7 +952,7 @@ extern "C" rgp_status rgp_psi_backward(rgp_handle h, int64_t N, int M, int Q, co
     hipLaunchKernelGGL(symmetrise_kernel, dim3((M * M + 255) / 256), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
     Psi2Out o{};
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
-    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
+    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1; o.pair_ws = L.pair_ws;
     const Psi2Plan pl = psi2_plan(h, N, M, QP, true, true);
     if ((st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid))) return st;
     const int tri = M * (M + 1) / 2;
@@ -1435,7 +1446,7 @@ extern "C" rgp_status rgp_layer_step(rgp_handle h, const rgp_layer_in* in, const
   {
     Psi2Out o{};
     o.p2_part = L.p2_part; o.dz_part = L.dz2_part; o.dlam_part = L.dlam2_part; o.wsum_part = L.wsum2_part;
-    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1;
+    o.gmu = L.gmu; o.gS = L.gS; o.accumulate = 1; o.pair_ws = L.pair_ws;
     prof_begin(h, (double)N * M * M * Q);
     const Psi2Plan pl = psi2_plan(h, N, M, QP, true, true);
     st = launch_psi2(h, true, true, N, M, Q, L.zt, L.rt, L.dLs, o, pl.grid);

@@ -105,9 +105,22 @@ struct Psi2Out {
   double* dlam_part;   // [nblk x QP]
   double* wsum_part;   // [nblk]                  sum of all weights (for dvar)
   double* gmu; double* gS; int accumulate;        // row gradients
+  double* pair_ws;     // workspace of the pair-form pass (psi2_pair_ws_doubles); nullptr: the sweep kernels only
 };
 rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q, const ZTerms& zt, const RowTerms& rt,
                        const double* dLs, const Psi2Out& out, int nblk);
+// Pair-form fused pass on the fp64 matrix pipe (rgp_psi2_pair.hip): geometry of one launch, whether a shape is supported, and
+// whether the handle's mode (rgp_set_psi2_pair / RGP_PSI2_PAIR) selects it for a fused forward + backward pass.
+struct PairGeom {
+  int M, QP, QT, TS, HS, OS, RS, PW, M2, P, G, Ppad, RR, NB;
+  int64_t ntiles;
+  size_t lds;
+};
+bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g);
+bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g);
+size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N);
+rgp_status launch_psi2_pair(rgp_handle h, const PairGeom& g, int64_t N, int Q, const ZTerms& zt, const RowTerms& rt,
+                            const double* dLs, const Psi2Out& out, double* ws);
 // out[i] = scale * sum_g part[g*stride + i], i < len (fixed order)
 void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const double* part, double* out, double scale,
                    int accumulate);

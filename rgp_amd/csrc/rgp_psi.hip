@@ -2266,6 +2266,12 @@ bool psi2_use_rows4(int M, int QP) {
 
 Psi2Plan psi2_plan(rgp_handle h, int64_t N, int M, int QP, bool fwd, bool bwd) {
   Psi2Plan pl;
+  PairGeom pg;
+  if (fwd && bwd && psi2_pair_selected(h, N, M, QP, pg)) {       // pair form: partials per row range / per row-kernel workgroup
+    pl.grid = pg.G * pg.RR;
+    pl.n_p2 = pg.RR; pl.n_dz = pg.NB + 1; pl.n_dl = pg.NB;
+    return pl;
+  }
   const int nt = (fwd && bwd && !h->deterministic) ? psi2_packed_teams(M, QP) : 0;
   if (nt >= 4) {
     int64_t g = h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0);     // one 512-thread workgroup per CU, nt rows in flight;
@@ -2409,6 +2415,9 @@ rgp_status launch_psi2(rgp_handle h, bool fwd, bool bwd, int64_t N, int M, int Q
                        const double* dLs, const Psi2Out& out, int nblk) {
   if (M > RGP_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: M > 128 is not supported by this build");
   if (zt.QP > RGP_MAX_QP) return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2: Q > 64 is not supported by this build");
+  PairGeom pg;
+  if (fwd && bwd && out.pair_ws && psi2_pair_selected(h, N, M, zt.QP, pg))
+    return launch_psi2_pair(h, pg, N, Q, zt, rt, dLs, out, out.pair_ws);
   Psi2Args a{};
   a.N = N; a.M = M; a.Q = Q; a.Zc = zt.Zc; a.ZcT = zt.ZcT; a.zd = zt.zd; a.lam = zt.lam; a.dLs = dLs;
   a.Xmu = rt.Xmu; a.d2 = rt.d2; a.g0 = rt.g0; a.o = out;
