@@ -30,6 +30,7 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#define PAIR_DEFAULT_MODE 0         // until the pair form beats the sweep kernels at the benchmark size
 #define PAIR_NT 4                 // pair tiles per wave (their C accumulators: 4 x QT x 4 doubles per lane)
 #define PAIR_WAVES 8
 #define PAIR_GROUP (PAIR_WAVES * PAIR_NT * 16)       // pairs per workgroup
@@ -67,45 +68,84 @@ static __device__ __forceinline__ void pair_ab(int p, int M, int P, int& a, int&
 
 struct PairArgs {
   int64_t N, ntiles;
-  int M, P, G, RR, HS, OS, PW, M2, tri, Ppad;
+  int M, P, G, RR, HS, RSP, PW, M2, tri, Ppad;
   const double *rec, *Zc, *lam, *dLs;
   double *PV, *Cpart, *p2_part;
+  double* dbg;          // per-phase cycle stamps of a -DPAIR_STAMPS build (nullptr otherwise)
 };
+#ifdef PAIR_STAMPS
+#define PSTAMP(i) do { const long long t1_ = __builtin_readcyclecounter(); st_[i] += t1_ - st0_; st0_ = t1_; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 
-// LDS image (doubles): Z [M][ZS] | exp table [256] | 2 x input record [d2 16 x TS | h' 16 x HS] | 2 x output tile [16][OS] |
-// 8 x transposition tile [16][17]
+// LDS image (doubles): Z [M][ZS] | exp table [256] | 2 x input record [d2 16 x TS | h' 16 x HS | pad to 1 KiB] |
+// 2 x V2 tile [16][HS] | 3 x T tile [16][TT] | 8 x transposition tile [16][17]
+//
+// Two roles.  The eight waves of a workgroup sit two to a SIMD (waves w and w + 4), and the two waves of a SIMD share its fp64
+// pipe: in step with each other they would wait for their LDS reads at the same moments and want the pipe at the same moments.
+// Every wave runs [GE(k): Gram, exponentials, V2 adds] [CT(k): C and T products] per step k, with ONE workgroup barrier per step:
+// waves 0-3 (role 0) pass it after CT(k), waves 4-7 (role 1) between GE(k) and CT(k).  Between two barriers role 0 therefore runs
+// GE(k+1), CT(k+1) while role 1 runs CT(k), GE(k+1): one wave of every SIMD is in the matrix-heavy half while the other is in
+// the exponentials.  What the barrier B_k guarantees: V2 tile k complete (all waves add it in GE(k)), T tile k - 1 complete (role
+// 1 adds T(k-1) after B_(k-1)).  After B_k every thread writes its slice of V2 tile k and T tile k - 1 to the partial buffer and
+// clears it; V2 tiles rotate over two buffers, T tiles over three (k - 1 being written out, k receiving role 1's adds, k + 1
+// role 0's).  The record of step k + 2 is requested right after B_k (LDS-DMA into the buffer of record k, which nobody reads
+// any more: role 1 carries the C product's right operand of step k in registers) and has landed before B_(k+1).
 template <int QP>
 __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
   constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, NT = PAIR_NT;
+  constexpr int TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;       // T tile row stride: = 16 mod 32
   extern __shared__ double lds[];
-  const int M = a.M, HS = a.HS, OS = a.OS;
-  const int RS = 16 * (TS + HS);
+  const int M = a.M, HS = a.HS;
+  const int RSP = a.RSP;                                                     // record length padded to a multiple of 128 doubles
   double* const Zl = lds;
-  double* const etab = Zl + ((M * ZS + 1) & ~1);
+  double* const etab = Zl + ((M * ZS + 127) & ~127);
   double* const inb = etab + PSI2_EXP_TAB;
-  double* const outb = inb + 2 * RS;
-  double* const tball = outb + 2 * 16 * OS;
+  double* const v2b = inb + 2 * RSP;
+  double* const ttb = v2b + 2 * 16 * HS;
+  double* const tball = ttb + 3 * 16 * TT;
+  double* const kptab = tball + PAIR_WAVES * 16 * 17;           // [512] -2 k_p of the workgroup's pairs
+  double* const pstab = kptab + PAIR_GROUP;                     // [512] pair sums of psi2 (the four row groups of a lane add here)
 
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool role1 = wave >= 4;
   const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
   const int64_t t0 = a.ntiles * rr / a.RR, t1 = a.ntiles * (rr + 1) / a.RR;
+  const int nsteps = (int)(t1 - t0);
   double* const tb = tball + wave * (16 * 17);
 
-  // ---- one-time set-up: Z image, exp table, zeroed output tiles, first record, per-lane pair constants
+  // record r of this workgroup -> LDS buffer r & 1, one 1-KiB piece per wave instruction
+  // (inline asm: the compiler, unable to tell the DMA's LDS destination from the tiles the waves read meanwhile, would wait for
+  // the transfer before the next LDS read; the waves wait for it themselves, with s_waitcnt vmcnt(0) in front of the barrier
+  // that precedes the record's first use)
+  auto request_record = [&](int r) {
+    const double* src = a.rec + (size_t)(t0 + r) * RSP + lane * 2;
+    const unsigned dst = (unsigned)(size_t)(inb + (r & 1) * RSP);
+    for (int ch = wave; ch * 128 < RSP; ch += PAIR_WAVES) {
+      const double* gsrc = src + ch * 128;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + ch * 1024);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+    }
+  };
+#define PAIR_BARRIER() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
+  // ---- one-time set-up: Z image, exp table, zeroed output tiles, first two records, per-lane pair constants
   for (int i = t; i < M * ZS; i += 512) {
     const int m = i / ZS, q = i - m * ZS;
     Zl[i] = (q < QP) ? a.Zc[(size_t)m * QP + q] : 0.0;
   }
   if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
-  for (int i = t; i < 2 * 16 * OS; i += 512) outb[i] = 0.0;
-  if (t0 < t1) {
-    const double2* src = reinterpret_cast<const double2*>(a.rec + (size_t)t0 * RS);
-    double2* dst = reinterpret_cast<double2*>(inb);
-    for (int i = t; i < RS / 2; i += 512) dst[i] = src[i];
-  }
+  for (int i = t; i < 2 * 16 * HS + 3 * 16 * TT; i += 512) v2b[i] = 0.0;
+  if (nsteps > 0) request_record(0);
+  if (nsteps > 1) request_record(1);
   int pkn[NT], pkt[NT][2];
-  double dl2[NT], kp[NT];
+  double dl2[NT];
+  double* const kpw = kptab + wave * (NT * 16) + c;             // this lane's entries: kpw[16 k]
+  double* const psw = pstab + wave * (NT * 16) + c;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int tau = (gi * PAIR_WAVES + wave) * NT + k;
@@ -116,7 +156,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
     dl2[k] = (p < a.P) ? a.dLs[(size_t)pa * M + pb] * (pa == pb ? 1.0 : 2.0) : 0.0;
     double s = 0.0;
     for (int q = 0; q < QP; ++q) s += a.lam[q] * a.Zc[(size_t)pa * QP + q] * a.Zc[(size_t)pb * QP + q];
-    kp[k] = 0.5 * s;
+    if (g == 0) { kpw[16 * k] = -s; psw[16 * k] = 0.0; }       // -2 k_p: the accumulators carry -2 E
     int w4[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -127,41 +167,85 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
     pkt[k][1] = w4[2] | (w4[3] << 16);
   }
   d4 Cacc[NT][QT];
-  double psum[NT];
 #pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    psum[k] = 0.0;
+  for (int k = 0; k < NT; ++k)
 #pragma unroll
     for (int j = 0; j < QT; ++j) Cacc[k][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  }
-  __syncthreads();
+  PAIR_BARRIER();
 
-  constexpr int NPRE = (16 * (TS + 112) / 2 + 511) / 512;       // double2 per thread of the largest record (HS <= 112)
-  for (int64_t s = t0; s < t1; ++s) {
-    const int buf = (int)((s - t0) & 1);
-    const double* const d2t = inb + buf * RS;                    // [16][TS]
-    const double* const hq = d2t + 16 * TS;                      // [16][HS]
-    double* const out = outb + buf * (16 * OS);                  // [16][OS]: V2 in columns [0, HS), T in [HS, HS + 16 QT)
-    const bool more = s + 1 < t1;
-    // next record: global loads now, LDS stores at the end of the step
-    double2 pre[NPRE];
-    if (more) {
-      const double2* src = reinterpret_cast<const double2*>(a.rec + (size_t)(s + 1) * RS);
+  // write-out slice of this thread: row t / 32 of the tile, columns t % 32 + 32 j.  Few loop invariants on purpose: two LDS
+  // offsets, one running pointer into the partial buffer.
+  const int wrow = t >> 5;
+  const int woff = wrow * HS + (t & 31), toff = wrow * TT + (t & 31);
+  const int vslots = (a.M2 - (t & 31) + 31) >> 5;                // column slots of this thread in a V2 row (0..4)
+  const int tslots = (QP - (t & 31) + 31) >> 5;                  // ... in a T row (0..2)
+  double* pvp = a.PV + ((size_t)t0 * 16 + wrow) * a.PW + (t & 31);     // row of tile k, advanced after B_k
+  int t3 = 2;                                                    // (k - 1) mod 3 at B_k
+  // After barrier B_k: V2 tile k and T tile k - 1 go to the partial buffer and are cleared, record k + 2 is requested.
+  auto after_barrier = [&](int k) {
+    if (k + 2 < nsteps) request_record(k + 2);
+    const int64_t left = a.N - (t0 + k) * 16;                    // valid rows of tile k
+    if (k < nsteps) {
+      double* const vrow = v2b + (k & 1) * (16 * HS) + woff;
+      const bool rok = wrow < left;
+      double v[4];
 #pragma unroll
-      for (int j = 0; j < NPRE; ++j) {
-        const int i = t + 512 * j;
-        pre[j] = src[i < RS / 2 ? i : RS / 2 - 1];
-      }
+      for (int j = 0; j < 4; ++j) v[j] = (j < vslots) ? vrow[32 * j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < vslots) {
+          vrow[32 * j] = 0.0;
+          if (rok) atomicAdd(&pvp[32 * j], v[j]);
+        }
     }
+    if (k >= 1) {
+      double* const trow = ttb + t3 * (16 * TT) + toff;
+      double* const prow = pvp - 16 * (int64_t)a.PW + a.M2;
+      double v[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v[j] = (j < tslots) ? trow[32 * j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (j < tslots) {
+          trow[32 * j] = 0.0;
+          if (wrow < left + 16) atomicAdd(&prow[32 * j], v[j]);  // rows of tile k - 1 that exist
+        }
+    }
+    pvp += 16 * (int64_t)a.PW;
+    t3 = (t3 == 2) ? 0 : t3 + 1;
+  };
+
+#ifdef PAIR_STAMPS
+  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st0_ = __builtin_readcyclecounter();
+#endif
+  for (int s = 0; s < nsteps; ++s) {
+#ifdef PAIR_SOLO                       // timing experiment: waves 4-7 only keep the barriers, waves 0-3 have their SIMDs to themselves
+    if (role1) { PAIR_BARRIER(); after_barrier(s); continue; }
+#endif
+    const double* const d2t = inb + (s & 1) * RSP;               // [16][TS]
+    const double* const hq = d2t + 16 * TS;                      // [16][HS]
+    double* const v2t = v2b + (s & 1) * (16 * HS);               // [16][HS]
+    double* const ttile = ttb + (s % 3) * (16 * TT);             // [16][TT]
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
       asm volatile("" : "+v"(pkn[k]), "+v"(pkt[k][0]), "+v"(pkt[k][1]));      // keep the derived addresses out of loop-invariant registers
     }
-
-    // ---- Gram: acc[k][16 rows x 16 pairs] = sum_q d2[n,q] z[a,q] z[b,q]
+    // ======== GE(s) ========
+    // the accumulators start at -2 (h'[n,a] + h'[n,b] + k_p), so that E = -acc / 2 after the Gram product and no LDS round trip
+    // sits between the product and the exponential
     d4 acc[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < NT; ++k) {
+      const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
+      const double kpk = kpw[16 * k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + g;
+        acc[k][r] = fma(-2.0, hq[row * HS + pa] + hq[row * HS + pb], kpk);
+      }
+    }
+    PSTAMP(0);
+    // Gram: acc[k][16 rows x 16 pairs] += sum_q d2[n,q] z[a,q] z[b,q]
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) {
       const double A = d2t[c * TS + 4 * kq + g];
@@ -172,35 +256,78 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
         acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, zz, acc[k], 0, 0, 0);
       }
     }
-    // ---- exponent, exp, weights, V2
+    PSTAMP(1);
+    // the exponentials, two pair tiles at a time: range reduction, the table entries in one batch of LDS reads, polynomial
     double w[NT][4];
+#pragma unroll
+    for (int k0 = 0; k0 < NT; k0 += 2) {
+      int sh[2][4];
+      double tj[2][4];
+#pragma unroll
+      for (int k = k0; k < k0 + 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double x = -0.5 * acc[k][r];
+          x = (x < -800.0) ? -800.0 : x;                                     // NaN stays NaN
+          const double tt = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);
+          const int n = __double2loint(tt);
+          const double nf = tt - 0x1.8p52;
+          double rr_ = fma(nf, -0x1.62e42fee00000p-9, x);
+          rr_ = fma(nf, -0x1.a39ef35793c76p-41, rr_);
+          w[k][r] = rr_;
+          sh[k - k0][r] = n >> 8;
+          tj[k - k0][r] = etab[n & (PSI2_EXP_TAB - 1)];
+        }
+#pragma unroll
+      for (int k = k0; k < k0 + 2; ++k) {
+        double ps = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double rr_ = w[k][r];
+          double q = fma_rrr(rr_, 0x1.5555555555555p-5, 0x1.5555555555555p-3);
+          q = fma_rrr(q, rr_, 0.5);
+          q = fma_rrr(q, rr_, 1.0);
+          q = q * rr_;
+          const double e = ldexp(fma(tj[k - k0][r], q, tj[k - k0][r]), sh[k - k0][r]);
+          ps += e;
+          w[k][r] = e * dl2[k];
+        }
+        atomicAdd(&psw[16 * k], ps);
+      }
+    }
+    // V2 adds in one batch (fire and forget), then the right operand of the C product (role 1 carries it across the barrier)
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
       const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
-      double ps = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 4 * r + g;
-        const double E = fma(-0.5, acc[k][r], (hq[row * HS + pa] + hq[row * HS + pb]) + kp[k]);
-        const double e = exp_tab_n(E, etab);
-        ps += e;
-        w[k][r] = e * dl2[k];
-        atomicAdd(&out[row * OS + pa], w[k][r]);
-        atomicAdd(&out[row * OS + pb], w[k][r]);
-      }
-      psum[k] += ps;
-    }
-    // ---- C[k][16 pairs x 16 q] += w^T d2   (K = the step's 16 rows)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int j = 0; j < QT; ++j) {
-        const double B = d2t[(4 * r + g) * TS + 16 * j + c];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) Cacc[k][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[k][r], B, Cacc[k][j], 0, 0, 0);
+        atomicAdd(&v2t[(4 * r + g) * HS + pa], w[k][r]);
+        atomicAdd(&v2t[(4 * r + g) * HS + pb], w[k][r]);
       }
     }
-    // ---- T[16 rows x 16 q] += w (z z)^T   (K = the tile's 16 pairs; the weights transposed through the wave's LDS tile)
+    double Bc[4][QT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < QT; ++j) Bc[r][j] = d2t[(4 * r + g) * TS + 16 * j + c];
+    PSTAMP(2);
+    // ======== CT(s) ========
+    // C[k][16 pairs x 16 q] += w^T d2   (K = the step's 16 rows)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < QT; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) Cacc[k][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[k][r], Bc[r][j], Cacc[k][j], 0, 0, 0);
+    PSTAMP(3);
+    if (role1) {
+      PAIR_BARRIER();                        // B_s for waves 4-7: between the C and the T product
+      PSTAMP(5);
+      after_barrier(s);
+      PSTAMP(6);
+    }
+    // T[16 rows x 16 q] += w (z z)^T   (K = the tile's 16 pairs; the weights transposed through the wave's LDS tile, the tile's
+    // 8 x QT z values read in one batch)
     d4 Tacc[QT];
 #pragma unroll
     for (int j = 0; j < QT; ++j) Tacc[j] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -214,44 +341,43 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       for (int kk = 0; kk < 4; ++kk) at[kk] = tb[c * 17 + 4 * kk + g];
       wave_lds_fence();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int pk = (pkt[k][kk >> 1] >> (16 * (kk & 1))) & 0xffff;
-        const int pa = pk & 0xff, pb = pk >> 8;
+      for (int h2 = 0; h2 < 2; ++h2) {
+        double zz[2][QT];
 #pragma unroll
-        for (int j = 0; j < QT; ++j) {
-          const double zz = Zl[pa * ZS + 16 * j + c] * Zl[pb * ZS + 16 * j + c];
-          Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], zz, Tacc[j], 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int pk = (pkt[k][h2] >> (16 * kk)) & 0xffff;
+          const int pa = pk & 0xff, pb = pk >> 8;
+#pragma unroll
+          for (int j = 0; j < QT; ++j) zz[kk][j] = Zl[pa * ZS + 16 * j + c] * Zl[pb * ZS + 16 * j + c];
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < QT; ++j) Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[2 * h2 + kk], zz[kk][j], Tacc[j], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < QT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&out[(4 * r + g) * OS + HS + 16 * j + c], Tacc[j][r]);
-    // ---- stage the next record, hand the finished output tile over
-    if (more) {
-      double2* dst = reinterpret_cast<double2*>(inb + (buf ^ 1) * RS);
-#pragma unroll
-      for (int j = 0; j < NPRE; ++j) {
-        const int i = t + 512 * j;
-        if (i < RS / 2) dst[i] = pre[j];
-      }
-    }
-    __syncthreads();
-    {
-      const int row = t >> 5;
-      const int64_t n = s * 16 + row;
-      double* const orow = out + row * OS;
-      double* const prow = a.PV + ((size_t)gi * a.N + (n < a.N ? n : 0)) * a.PW;
-      for (int col = t & 31; col < a.PW; col += 32) {
-        const int src = col < a.M2 ? col : HS + (col - a.M2);
-        const double v = orow[src];
-        orow[src] = 0.0;
-        if (n < a.N) prow[col] = v;
-      }
+      for (int r = 0; r < 4; ++r) atomicAdd(&ttile[(4 * r + g) * TT + 16 * j + c], Tacc[j][r]);
+    PSTAMP(4);
+    if (!role1) {
+      PAIR_BARRIER();                        // B_s for waves 0-3
+      PSTAMP(5);
+      after_barrier(s);
+      PSTAMP(6);
     }
   }
+  // role 1's T adds of the last step came after the last barrier: one more, then the last T tile leaves
+  PAIR_BARRIER();
+  after_barrier(nsteps);
 
+#ifdef PAIR_STAMPS
+  if (a.dbg && lane == 0) {
+    st_[7] = nsteps;
+    for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = (double)st_[i];
+  }
+#endif
   // ---- flush: C partial of this (row range, pair group), pair sums of psi2
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
@@ -263,9 +389,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       for (int r = 0; r < 4; ++r)
         if (q < QP) a.Cpart[((size_t)rr * a.Ppad + 16 * tau + 4 * r + g) * QP + q] = Cacc[k][j][r];
     }
-    double ps = psum[k];
-    ps += __shfl_xor(ps, 16);
-    ps += __shfl_xor(ps, 32);
+    const double ps = psw[16 * k];
     if (g == 0 && ((pkn[k] >> 16) & 1)) {
       const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
       const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
@@ -280,15 +404,15 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 // Rows beyond N get d2 = 0 and h' = -inf (their exponentials are 0).
 // ------------------------------------------------------------------------------------------------------------------
 template <int QP>
-__global__ void __launch_bounds__(256) psi2_pair_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int HS,
+__global__ void __launch_bounds__(256) psi2_pair_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int HS, const int RS,
                                                               const double* __restrict__ Zc, const double* __restrict__ lam,
                                                               const double* __restrict__ Xmu, const double* __restrict__ d2,
-                                                              const double* __restrict__ g0, double* __restrict__ rec) {
+                                                              const double* __restrict__ g0, double* __restrict__ rec,
+                                                              double* __restrict__ PV, const int PW) {
   constexpr int QT = (QP + 15) / 16, TS = 16 * QT + 1;
   __shared__ __attribute__((aligned(16))) double2 dd[16 * QP];          // (d2, d2 mu)
   __shared__ double gs[16];
   const int t = threadIdx.x, m = t & 127, rh = t >> 7;
-  const int RS = 16 * (TS + HS);
   const bool act = m < M;
   double z[QP];
   double ellq = 0.0;
@@ -300,6 +424,10 @@ __global__ void __launch_bounds__(256) psi2_pair_prep_kernel(const int64_t N, co
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t n0 = tile * 16;
     double* const r = rec + (size_t)tile * RS;
+    {                                                      // the pair groups ADD their sums over pairs into this tile's rows
+      const int64_t lim = (N - n0 < 16 ? N - n0 : 16) * PW;
+      for (int i = t; i < lim; i += 256) PV[n0 * PW + i] = 0.0;
+    }
     __syncthreads();
     for (int i = t; i < 16 * QP; i += 256) {
       const int row = i / QP;
@@ -501,8 +629,8 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   g.QT = (QP + 15) / 16;
   g.TS = 16 * g.QT + 1;
   g.HS = pair_hs(M);
-  g.OS = (g.HS + 16 * g.QT + 31) / 32 * 32 + 16;
-  g.RS = 16 * (g.TS + g.HS);
+  g.OS = ((16 * g.QT) % 32 == 16) ? 16 * g.QT : 16 * g.QT + 16;      // row stride of the T tiles (= 16 mod 32)
+  g.RS = (16 * (g.TS + g.HS) + 127) / 128 * 128;                       // record length: whole 1-KiB pieces
   g.M2 = (M + 1) & ~1;
   g.PW = g.M2 + QP;
   g.P = M * (M + 1) / 2;
@@ -516,8 +644,8 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int64_t nb = 2 * (int64_t)h->num_cu;
   if (nb > g.ntiles) nb = g.ntiles;
   g.NB = (int)nb;
-  const size_t zs = (size_t)(M * g.TS + 1) & ~(size_t)1;
-  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17) * sizeof(double);
+  const size_t zs = (size_t)(M * g.TS + 127) & ~(size_t)127;
+  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.HS + 3 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17 + 2 * PAIR_GROUP) * sizeof(double);
   return g.lds <= 160 * 1024;
 }
 
@@ -526,7 +654,7 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int mode = h->psi2_pair;
   if (mode < 0) {
     static int env_mode = -2;
-    if (env_mode == -2) { const char* e = getenv("RGP_PSI2_PAIR"); env_mode = e ? atoi(e) : 1; }
+    if (env_mode == -2) { const char* e = getenv("RGP_PSI2_PAIR"); env_mode = e ? atoi(e) : PAIR_DEFAULT_MODE; }
     mode = env_mode;
   }
   if (mode <= 0 || h->deterministic) return false;
@@ -537,7 +665,7 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
 
 size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N) {
   auto r = [](size_t n) { return (n + 31) & ~(size_t)31; };
-  return r((size_t)g.ntiles * g.RS) + r((size_t)g.G * N * g.PW) + r((size_t)g.RR * g.Ppad * g.QP) + r((size_t)g.Ppad * g.QP) + 64;
+  return r((size_t)g.ntiles * g.RS) + r((size_t)N * g.PW) + r((size_t)g.RR * g.Ppad * g.QP) + r((size_t)g.Ppad * g.QP) + 64;
 }
 
 template <int QP>
@@ -546,24 +674,41 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   auto r = [](size_t n) { return (n + 31) & ~(size_t)31; };
   double* rec = ws;
   double* PV = rec + r((size_t)g.ntiles * g.RS);
-  double* Cpart = PV + r((size_t)g.G * N * g.PW);
+  double* Cpart = PV + r((size_t)N * g.PW);
   double* Csum = Cpart + r((size_t)g.RR * g.Ppad * g.QP);
   const int M = g.M;
   int prep_grid = (int)(g.ntiles < 1024 ? g.ntiles : 1024);
-  hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3(prep_grid), dim3(256), 0, s, N, g.ntiles, M, g.HS, zt.Zc, zt.lam, rt.Xmu,
-                     rt.d2, rt.g0, rec);
+  hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3(prep_grid), dim3(256), 0, s, N, g.ntiles, M, g.HS, g.RS, zt.Zc, zt.lam, rt.Xmu,
+                     rt.d2, rt.g0, rec, PV, g.PW);
   PairArgs a{};
-  a.N = N; a.ntiles = g.ntiles; a.M = M; a.P = g.P; a.G = g.G; a.RR = g.RR; a.HS = g.HS; a.OS = g.OS; a.PW = g.PW; a.M2 = g.M2;
+  a.N = N; a.ntiles = g.ntiles; a.M = M; a.P = g.P; a.G = g.G; a.RR = g.RR; a.HS = g.HS; a.RSP = g.RS; a.PW = g.PW; a.M2 = g.M2;
   a.tri = M * (M + 1) / 2; a.Ppad = g.Ppad;
   a.rec = rec; a.Zc = zt.Zc; a.lam = zt.lam; a.dLs = dLs; a.PV = PV; a.Cpart = Cpart; a.p2_part = o.p2_part;
   hipError_t e = hipFuncSetAttribute((const void*)psi2_pair_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
   if (e != hipSuccess) return e;
+#ifdef PAIR_STAMPS
+  static double* dbg_s = nullptr;
+  if (!dbg_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbg_s, 256 * 8 * 8 * sizeof(double));
+  a.dbg = dbg_s;
+#endif
   hipLaunchKernelGGL((psi2_pair_kernel<QP>), dim3(g.G * g.RR), dim3(512), g.lds, s, a);
+#ifdef PAIR_STAMPS
+  if (dbg_s && g.G * g.RR <= 256) {
+    (void)hipStreamSynchronize(s);
+    static double hb[256 * 8 * 8];
+    (void)hipMemcpy(hb, dbg_s, sizeof(hb), hipMemcpyDeviceToHost);
+    double acc[8] = {0};
+    const int nw = g.G * g.RR * 8;
+    for (int w = 0; w < nw; ++w) for (int i = 0; i < 7; ++i) acc[i] += hb[w * 8 + i] / (hb[w * 8 + 7] > 0 ? hb[w * 8 + 7] : 1) / nw;
+    fprintf(stderr, "pair QP=%d steps/wg %.0f cycles/step (mean over waves): h-init %.0f gram %.0f exp+v2 %.0f C %.0f T %.0f barrier-wait %.0f after-barrier %.0f\n", QP,
+            hb[7], acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+  }
+#endif
   // row gradients, dinv_l / weight-sum partials, B slabs
   const size_t lr = (5 * 16 * (size_t)QP + 16 + (size_t)M * (QP + 1) + 16 * (size_t)(g.M2 + 1)) * sizeof(double);
   e = hipFuncSetAttribute((const void*)psi2_pair_rows_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, g.ntiles, M, Q, g.G, g.PW, g.M2, PV, zt.Zc, zt.lam,
+  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, g.ntiles, M, Q, 1, g.PW, g.M2, PV, zt.Zc, zt.lam,
                      rt.Xmu, rt.d2, o.gmu, o.gS, o.accumulate, o.dz_part, o.dlam_part, o.wsum_part);
   // dZ3 from the C partials: one more slab behind the row kernel's
   launch_reduce(s, g.RR, (int64_t)g.Ppad * QP, (int64_t)g.Ppad * QP, Cpart, Csum, 1.0, 0);

@@ -76,7 +76,8 @@ def test_many_steps_per_workgroup_and_minibatch():
     tile); then a minibatch of two of three ragged sequences (qU_ratio = 2/3)."""
     o, g = build_pair(wins=(0, 20, 20), nDims=(16, 1, 1), n_seq=1, T=7303, M=100, U_win=20, u_dim=1, y_dim=16, fast_psi=True,
                       chunk=512)
-    compare(o, g)            # default mode: M = 100 and 7283 rows select the pair form by themselves
+    g.handle.set_psi2_pair(1)
+    compare(o, g)            # mode 1: M = 100 and 7283 rows select the pair form by themselves
     o, g = build_pair(wins=(0, 6, 6), nDims=(3, 2, 2), n_seq=3, T=4001, M=12, U_win=6, ragged=True, n_total=3, fast_psi=True,
                       chunk=512)
     g.handle.set_psi2_pair(2)
