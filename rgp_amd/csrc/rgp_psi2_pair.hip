@@ -31,7 +31,9 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define PAIR_DEFAULT_MODE 0         // until the pair form beats the sweep kernels at the benchmark size
+#ifndef PAIR_NT
 #define PAIR_NT 4                 // pair tiles per wave (their C accumulators: 4 x QT x 4 doubles per lane)
+#endif
 #define PAIR_WAVES 8
 #define PAIR_GROUP (PAIR_WAVES * PAIR_NT * 16)       // pairs per workgroup
 
@@ -68,45 +70,58 @@ static __device__ __forceinline__ void pair_ab(int p, int M, int P, int& a, int&
 
 struct PairArgs {
   int64_t N, ntiles;
-  int M, P, G, RR, HS, RSP, PW, M2, tri, Ppad;
+  int M, P, G, RR, PW, M2, tri, Ppad;
   const double *rec, *Zc, *lam, *dLs;
   double *PV, *Cpart, *p2_part;
   double* dbg;          // per-phase cycle stamps of a -DPAIR_STAMPS build (nullptr otherwise)
 };
 #ifdef PAIR_STAMPS
-#define PSTAMP(i) do { const long long t1_ = __builtin_readcyclecounter(); st_[i] += t1_ - st0_; st0_ = t1_; } while (0)
+// the counter reads are issued where the phases end and collected once per step: a read that was waited for on the spot would
+// drain the wave's LDS queue at every stamp
+#define PSTAMP(i) asm volatile("s_memtime %0" : "=s"(sq_[i]))
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
 
-// LDS image (doubles): Z [M][ZS] | exp table [256] | 2 x input record [d2 16 x TS | h' 16 x HS | pad to 1 KiB] |
-// 2 x V2 tile [16][HS] | 3 x T tile [16][TT] | 8 x transposition tile [16][17]
+// LDS image (doubles; every offset but the length of the Z image is a compile-time constant, so that most addresses are a
+// per-lane register plus an immediate): exp table [256] | 2 x input record [d2 16 x TS | h' 16 x HS | pad to 1 KiB] |
+// 2 x V2 tile [16][HS] | 3 x T tile [16][TT] | 8 x transposition tile [16][17] | -2 k_p [512] | pair sums [512] | c_p dLs [512] |
+// Z [M][ZS]
 //
 // Two roles.  The eight waves of a workgroup sit two to a SIMD (waves w and w + 4), and the two waves of a SIMD share its fp64
 // pipe: in step with each other they would wait for their LDS reads at the same moments and want the pipe at the same moments.
-// Every wave runs [GE(k): Gram, exponentials, V2 adds] [CT(k): C and T products] per step k, with ONE workgroup barrier per step:
-// waves 0-3 (role 0) pass it after CT(k), waves 4-7 (role 1) between GE(k) and CT(k).  Between two barriers role 0 therefore runs
-// GE(k+1), CT(k+1) while role 1 runs CT(k), GE(k+1): one wave of every SIMD is in the matrix-heavy half while the other is in
-// the exponentials.  What the barrier B_k guarantees: V2 tile k complete (all waves add it in GE(k)), T tile k - 1 complete (role
-// 1 adds T(k-1) after B_(k-1)).  After B_k every thread writes its slice of V2 tile k and T tile k - 1 to the partial buffer and
-// clears it; V2 tiles rotate over two buffers, T tiles over three (k - 1 being written out, k receiving role 1's adds, k + 1
-// role 0's).  The record of step k + 2 is requested right after B_k (LDS-DMA into the buffer of record k, which nobody reads
-// any more: role 1 carries the C product's right operand of step k in registers) and has landed before B_(k+1).
+// Every wave runs [GE(k): Gram, exponentials, V2 adds] [C(k)] [T(k)] per step k, with ONE workgroup barrier per step: waves
+// 0-3 (role 0) pass it after T(k), waves 4-7 (role 1) between C(k) and T(k).  Between two barriers role 0 therefore runs
+// GE(k+1), C(k+1), T(k+1) while role 1 runs T(k), GE(k+1), C(k+1).  What the barrier B_k guarantees: V2 tile k complete (all
+// waves add it in GE(k)), T tile k - 1 complete (role 1 adds T(k-1) after B_(k-1)).  After B_k every thread adds its slice of V2
+// tile k and T tile k - 1 to the global sums and clears it; V2 tiles rotate over two buffers, T tiles over three (k - 1 being
+// written out, k receiving role 1's adds, k + 1 role 0's).  The record of step k + 2 is requested right after B_k (LDS-DMA into
+// the buffer of record k, which nobody reads any more) and has landed before B_(k+1).
+//
+// Software pipeline.  The register allocator works at the 256-register limit of two waves per SIMD and, left alone, waits for
+// every LDS read right after issuing it.  The step is therefore written in the order it should issue -- operands of the next
+// group of matrix instructions are requested before the current group is issued -- with scheduling barriers between the groups.
+#define PAIR_HS 112               // row stride of the h' and V2 tiles (= 16 mod 32: the four row groups of a wave on disjoint banks); M <= 112
+#define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
 template <int QP>
 __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
-  constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, NT = PAIR_NT;
+  constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, NT = PAIR_NT, HS = PAIR_HS;
   constexpr int TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;       // T tile row stride: = 16 mod 32
+  constexpr int RSP = (16 * (TS + HS) + 127) / 128 * 128;                    // record length: whole 1-KiB pieces
+  constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * 16 * HS, O_TB = O_TT + 3 * 16 * TT,
+                O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + PAIR_GROUP, O_DL = O_PS + PAIR_GROUP, O_Z = O_DL + PAIR_GROUP;
   extern __shared__ double lds[];
-  const int M = a.M, HS = a.HS;
-  const int RSP = a.RSP;                                                     // record length padded to a multiple of 128 doubles
-  double* const Zl = lds;
-  double* const etab = Zl + ((M * ZS + 127) & ~127);
-  double* const inb = etab + PSI2_EXP_TAB;
-  double* const v2b = inb + 2 * RSP;
-  double* const ttb = v2b + 2 * 16 * HS;
-  double* const tball = ttb + 3 * 16 * TT;
-  double* const kptab = tball + PAIR_WAVES * 16 * 17;           // [512] -2 k_p of the workgroup's pairs
-  double* const pstab = kptab + PAIR_GROUP;                     // [512] pair sums of psi2 (the four row groups of a lane add here)
+  // LDS operands are addressed by their byte offset in the workgroup's LDS image: the kernel has no static LDS, so the dynamic
+  // image starts at offset 0 and an offset is the whole address (no base register, no add in front of every access)
+  typedef __attribute__((address_space(3))) double lds_f64;
+#define LDSD(off) (*(lds_f64*)(unsigned)(off))
+#define LDSP(off) ((double*)(lds_f64*)(unsigned)(off))
+  const int M = a.M;
+  double* const Zl = lds + O_Z;
+  double* const etab = lds + O_ETAB;
+  double* const inb = lds + O_INB;
+  double* const v2b = lds + O_V2;
+  double* const ttb = lds + O_TT;
 
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -114,7 +129,6 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
   const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
   const int64_t t0 = a.ntiles * rr / a.RR, t1 = a.ntiles * (rr + 1) / a.RR;
   const int nsteps = (int)(t1 - t0);
-  double* const tb = tball + wave * (16 * 17);
 
   // record r of this workgroup -> LDS buffer r & 1, one 1-KiB piece per wave instruction
   // (inline asm: the compiler, unable to tell the DMA's LDS destination from the tiles the waves read meanwhile, would wait for
@@ -142,21 +156,24 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
   for (int i = t; i < 2 * 16 * HS + 3 * 16 * TT; i += 512) v2b[i] = 0.0;
   if (nsteps > 0) request_record(0);
   if (nsteps > 1) request_record(1);
-  int pkn[NT], pkt[NT][2];
-  double dl2[NT];
-  double* const kpw = kptab + wave * (NT * 16) + c;             // this lane's entries: kpw[16 k]
-  double* const psw = pstab + wave * (NT * 16) + c;
+  // per-lane constants: LDS byte offsets of this lane's operands (pair of tile k in the accumulator layout: column c), the
+  // pairs 4 kk + g of the tile packed for the T product's right operand, c_p dLs
+  int pvalid = 0, pkt[NT][2];
+  int pa8[NT], pb8[NT];                                          // 8 a, 8 b of the lane's pair of tile k: every operand address derives from them
+  const int kpo = (O_KP + wave * (NT * 16) + c) * 8;
+  constexpr int pso_d = (O_PS - O_KP) * 8, dlo_d = (O_DL - O_KP) * 8;     // pair sums and c_p dLs: the same slot of the next tables
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int tau = (gi * PAIR_WAVES + wave) * NT + k;
     int pa, pb;
     const int p = 16 * tau + c;
     pair_ab(p, M, a.P, pa, pb);
-    pkn[k] = pa | (pb << 8) | ((p < a.P ? 1 : 0) << 16);
-    dl2[k] = (p < a.P) ? a.dLs[(size_t)pa * M + pb] * (pa == pb ? 1.0 : 2.0) : 0.0;
+    pvalid |= (p < a.P ? 1 : 0) << k;
+    pa8[k] = pa * 8; pb8[k] = pb * 8;
+    const double dlv = (p < a.P) ? a.dLs[(size_t)pa * M + pb] * (pa == pb ? 1.0 : 2.0) : 0.0;
     double s = 0.0;
     for (int q = 0; q < QP; ++q) s += a.lam[q] * a.Zc[(size_t)pa * QP + q] * a.Zc[(size_t)pb * QP + q];
-    if (g == 0) { kpw[16 * k] = -s; psw[16 * k] = 0.0; }       // -2 k_p: the accumulators carry -2 E
+    if (g == 0) { LDSD(kpo + 128 * k) = 0.5 * s; LDSD(kpo + pso_d + 128 * k) = 0.0; LDSD(kpo + dlo_d + 128 * k) = dlv; }       // k_p
     int w4[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -166,6 +183,15 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
     pkt[k][0] = w4[0] | (w4[1] << 16);
     pkt[k][1] = w4[2] | (w4[3] << 16);
   }
+  // The lane's operand offsets (8 c and 8 g times a stride) are recomputed from the thread index where a phase needs them instead
+  // of occupying registers through the whole step.
+  auto lane8 = [&](int& c8, int& g8) {
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    c8 = (tl & 15) << 3;
+    g8 = (tl >> 1) & 0x18;
+  };
+  const int tbase = (O_TB + wave * (16 * 17)) * 8;                // this wave's transposition tile
   d4 Cacc[NT][QT];
 #pragma unroll
   for (int k = 0; k < NT; ++k)
@@ -174,16 +200,17 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
   PAIR_BARRIER();
 
   // write-out slice of this thread: row t / 32 of the tile, columns t % 32 + 32 j.  Few loop invariants on purpose: two LDS
-  // offsets, one running pointer into the partial buffer.
-  const int wrow = t >> 5;
-  const int woff = wrow * HS + (t & 31), toff = wrow * TT + (t & 31);
-  const int vslots = (a.M2 - (t & 31) + 31) >> 5;                // column slots of this thread in a V2 row (0..4)
-  const int tslots = (QP - (t & 31) + 31) >> 5;                  // ... in a T row (0..2)
-  double* pvp = a.PV + ((size_t)t0 * 16 + wrow) * a.PW + (t & 31);     // row of tile k, advanced after B_k
+  // offsets, one running pointer into the sums.
+  double* pvp = a.PV + ((size_t)t0 * 16 + (t >> 5)) * a.PW + (t & 31);     // row of tile k, advanced after B_k
   int t3 = 2;                                                    // (k - 1) mod 3 at B_k
-  // After barrier B_k: V2 tile k and T tile k - 1 go to the partial buffer and are cleared, record k + 2 is requested.
+  // After barrier B_k: V2 tile k and T tile k - 1 are added to the global sums and cleared, record k + 2 is requested.
   auto after_barrier = [&](int k) {
-    if (k + 2 < nsteps) request_record(k + 2);
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));                                 // the slice's offsets are recomputed here, not kept across the step
+    const int wrow = tq >> 5, wcol = tq & 31;
+    const int woff = wrow * HS + wcol, toff = wrow * TT + wcol;
+    const int vslots = (a.M2 - wcol + 31) >> 5;                  // column slots of this thread in a V2 row (0..4)
+    const int tslots = (QP - wcol + 31) >> 5;                    // ... in a T row (0..2)
     const int64_t left = a.N - (t0 + k) * 16;                    // valid rows of tile k
     if (k < nsteps) {
       double* const vrow = v2b + (k & 1) * (16 * HS) + woff;
@@ -213,61 +240,99 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
     }
     pvp += 16 * (int64_t)a.PW;
     t3 = (t3 == 2) ? 0 : t3 + 1;
+    if (k + 2 < nsteps) request_record(k + 2);                   // last: no register reload may follow it before the next barrier
   };
 
 #ifdef PAIR_STAMPS
-  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st0_ = __builtin_readcyclecounter();
+  long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long sq_[13], sprev_ = __builtin_readcyclecounter();
 #endif
+  int tt3 = 0;                                                   // s mod 3
   for (int s = 0; s < nsteps; ++s) {
-#ifdef PAIR_SOLO                       // timing experiment: waves 4-7 only keep the barriers, waves 0-3 have their SIMDs to themselves
-    if (role1) { PAIR_BARRIER(); after_barrier(s); continue; }
-#endif
-    const double* const d2t = inb + (s & 1) * RSP;               // [16][TS]
-    const double* const hq = d2t + 16 * TS;                      // [16][HS]
-    double* const v2t = v2b + (s & 1) * (16 * HS);               // [16][HS]
-    double* const ttile = ttb + (s % 3) * (16 * TT);             // [16][TT]
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      asm volatile("" : "+v"(pkn[k]), "+v"(pkt[k][0]), "+v"(pkt[k][1]));      // keep the derived addresses out of loop-invariant registers
-    }
+    const int inB = (O_INB + (s & 1) * RSP) * 8;                 // d2 tile [16][TS] of this step's record
+    const int hB = inB + 16 * TS * 8;                            // h' tile [16][HS]
+    const int vB = (O_V2 + (s & 1) * (16 * HS)) * 8;             // V2 tile [16][HS]
+    const int tBs = (O_TT + tt3 * (16 * TT)) * 8;                // T tile [16][TT]
+    tt3 = (tt3 == 2) ? 0 : tt3 + 1;
     // ======== GE(s) ========
-    // the accumulators start at -2 (h'[n,a] + h'[n,b] + k_p), so that E = -acc / 2 after the Gram product and no LDS round trip
-    // sits between the product and the exponential
+    // group 0: the reads of the step's head in one batch: -2 k_p and the 32 h' values; the first Gram operands follow once half of
+    // them have been consumed.  The accumulators start at h'[n,a] + h'[n,b] + k_p and the record holds -d2 / 2: E = acc after the Gram product, no
+    // LDS round trip between the product and the exponential
+    double za[NT], zb[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) { asm volatile("" : "+v"(pa8[k]), "+v"(pb8[k])); }      // the derived addresses are recomputed per step, not kept
+    int c8, g8;
+    lane8(c8, g8);
+    const int gH = g8 * HS, zc = O_Z * 8 + g8, aoff = c8 * TS + g8;
     d4 acc[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
-      const double kpk = kpw[16 * k];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * r + g;
-        acc[k][r] = fma(-2.0, hq[row * HS + pa] + hq[row * HS + pb], kpk);
-      }
-    }
-    PSTAMP(0);
-    // Gram: acc[k][16 rows x 16 pairs] += sum_q d2[n,q] z[a,q] z[b,q]
-#pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) {
-      const double A = d2t[c * TS + 4 * kq + g];
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
-        const double zz = Zl[pa * ZS + 4 * kq + g] * Zl[pb * ZS + 4 * kq + g];
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, zz, acc[k], 0, 0, 0);
-      }
-    }
-    PSTAMP(1);
-    // the exponentials, two pair tiles at a time: range reduction, the table entries in one batch of LDS reads, polynomial
-    double w[NT][4];
+    double A0, A1;
+    int zoA[NT], zoB[NT];
+    // two pair tiles at a time (the 36 reads of all four at once would not fit the registers next to the accumulators)
 #pragma unroll
     for (int k0 = 0; k0 < NT; k0 += 2) {
-      int sh[2][4];
-      double tj[2][4];
+      double kpv[2], hA[2][4], hBv[2][4];
 #pragma unroll
-      for (int k = k0; k < k0 + 2; ++k)
+      for (int k = k0; k < k0 + 2 && k < NT; ++k) {
+        kpv[k - k0] = LDSD(kpo + 128 * k);
+        int oa = pa8[k] + gH + hB, ob = pb8[k] + gH + hB;
+        asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { hA[k - k0][r] = LDSD(oa + r * (4 * HS * 8)); hBv[k - k0][r] = LDSD(ob + r * (4 * HS * 8)); }
+      }
+      if (k0 + 2 >= NT) {                    // behind the last h' reads: the first Gram operands
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          zoA[k] = pa8[k] * ZS + zc; zoB[k] = pb8[k] * ZS + zc;
+          asm volatile("" : "+v"(zoA[k]), "+v"(zoB[k]));         // one register per tile side; the k-step goes into the instruction's offset
+        }
+        A0 = LDSD(inB + aoff); A1 = (KQ > 1) ? LDSD(inB + aoff + 32) : 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { za[k] = LDSD(zoA[k]); zb[k] = LDSD(zoB[k]); }
+      }
+      PAIR_SB();
+#pragma unroll
+      for (int k = k0; k < k0 + 2 && k < NT; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[k][r] = (hA[k - k0][r] + hBv[k - k0][r]) + kpv[k - k0];
+      PAIR_SB();
+    }
+    PSTAMP(0);
+    // Gram: acc[k][16 rows x 16 pairs] += sum_q d2[n,q] z[a,q] z[b,q]; the operands of k-step kq + 1 are requested before the
+    // matrix instructions of k-step kq are issued
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      double zan[NT], zbn[NT], A2 = 0.0;
+      if (kq + 1 < KQ) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { zan[k] = LDSD(zoA[k] + 32 * (kq + 1)); zbn[k] = LDSD(zoB[k] + 32 * (kq + 1)); }
+      }
+      if (kq + 2 < KQ) A2 = LDSD(inB + aoff + 32 * (kq + 2));
+      double zz[NT];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) zz[k] = za[k] * zb[k];
+      PAIR_SB();
+#pragma unroll
+      for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, zz[k], acc[k], 0, 0, 0);
+      PAIR_SB();
+      if (kq + 1 < KQ) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { za[k] = zan[k]; zb[k] = zbn[k]; }
+      }
+      A0 = A1; A1 = A2;
+    }
+    PSTAMP(1);
+    // the 16 exponentials: range reduction and table read of both halves first, then the polynomials
+    double w[NT][4], tj[NT][4], dl2[NT];
+    int sh[NT][4];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) dl2[k] = LDSD(kpo + dlo_d + 128 * k);
+#pragma unroll
+    for (int k0 = 0; k0 < NT; k0 += 2) {
+#pragma unroll
+      for (int k = k0; k < k0 + 2 && k < NT; ++k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double x = -0.5 * acc[k][r];
+          double x = acc[k][r];
           x = (x < -800.0) ? -800.0 : x;                                     // NaN stays NaN
           const double tt = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);
           const int n = __double2loint(tt);
@@ -275,50 +340,95 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
           double rr_ = fma(nf, -0x1.62e42fee00000p-9, x);
           rr_ = fma(nf, -0x1.a39ef35793c76p-41, rr_);
           w[k][r] = rr_;
-          sh[k - k0][r] = n >> 8;
-          tj[k - k0][r] = etab[n & (PSI2_EXP_TAB - 1)];
+          sh[k][r] = n >> 8;
+          tj[k][r] = LDSD(O_ETAB * 8 + ((n & (PSI2_EXP_TAB - 1)) << 3));
         }
-#pragma unroll
-      for (int k = k0; k < k0 + 2; ++k) {
-        double ps = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double rr_ = w[k][r];
-          double q = fma_rrr(rr_, 0x1.5555555555555p-5, 0x1.5555555555555p-3);
-          q = fma_rrr(q, rr_, 0.5);
-          q = fma_rrr(q, rr_, 1.0);
-          q = q * rr_;
-          const double e = ldexp(fma(tj[k - k0][r], q, tj[k - k0][r]), sh[k - k0][r]);
-          ps += e;
-          w[k][r] = e * dl2[k];
-        }
-        atomicAdd(&psw[16 * k], ps);
-      }
+      PAIR_SB();
     }
-    // V2 adds in one batch (fire and forget), then the right operand of the C product (role 1 carries it across the barrier)
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-      const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
+      double ps = 0.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        atomicAdd(&v2t[(4 * r + g) * HS + pa], w[k][r]);
-        atomicAdd(&v2t[(4 * r + g) * HS + pb], w[k][r]);
+        const double rr_ = w[k][r];
+        double q = fma_rrr(rr_, 0x1.5555555555555p-5, 0x1.5555555555555p-3);
+        q = fma_rrr(q, rr_, 0.5);
+        q = fma_rrr(q, rr_, 1.0);
+        q = q * rr_;
+        const double e = ldexp(fma(tj[k][r], q, tj[k][r]), sh[k][r]);
+        ps += e;
+        w[k][r] = e * dl2[k];
+      }
+      atomicAdd(LDSP(kpo + pso_d + 128 * k), ps);
+    }
+    PAIR_SB();
+    // right operand of the C product: requested now, it arrives under the V2 adds
+    double Bc[4][QT];
+    {
+      int c8b, g8b;
+      lane8(c8b, g8b);
+      int boff = g8b * TS + c8b + inB;                           // C product: right operand d2[row 4 r + g][16 j + c]
+      asm volatile("" : "+v"(boff));
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) Bc[r][j] = LDSD(boff + (4 * r * TS + 16 * j) * 8);
+    }
+    // V2 adds in one batch (fire and forget: they drain under the C product)
+    int gHv;
+    { int c8v, g8v; lane8(c8v, g8v); gHv = g8v * HS + vB; }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      int oa = pa8[k] + gHv, ob = pb8[k] + gHv;
+      asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(LDSP(oa + r * (4 * HS * 8)), w[k][r]);
+        atomicAdd(LDSP(ob + r * (4 * HS * 8)), w[k][r]);
       }
     }
-    double Bc[4][QT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int j = 0; j < QT; ++j) Bc[r][j] = d2t[(4 * r + g) * TS + 16 * j + c];
+    PAIR_SB();
     PSTAMP(2);
-    // ======== CT(s) ========
-    // C[k][16 pairs x 16 q] += w^T d2   (K = the step's 16 rows)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
+    // ======== C(s): C[k][16 pairs x 16 q] += w^T d2 (K = the step's 16 rows).  Behind the first quarter of its matrix
+    // instructions the first pair tile's weights go through the transposition tile and the first z values of the T product are
+    // requested ========
+    auto c_quarter = [&](int r) {
 #pragma unroll
       for (int j = 0; j < QT; ++j)
 #pragma unroll
         for (int k = 0; k < NT; ++k) Cacc[k][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[k][r], Bc[r][j], Cacc[k][j], 0, 0, 0);
+    };
+    // z values of k-step kk of pair tile k for the T product: rows of the pair 4 kk + g, columns 16 j + c
+    auto t_reads = [&](int zto, int k, int kk, double (&zra)[QT], double (&zrb)[QT]) {
+      const int pk = (pkt[k][kk >> 1] >> (16 * (kk & 1))) & 0xffff;
+      int oa = (pk & 0xff) * (ZS * 8) + zto, ob = (pk >> 8) * (ZS * 8) + zto;
+      asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+      for (int j = 0; j < QT; ++j) { zra[j] = LDSD(oa + 128 * j); zrb[j] = LDSD(ob + 128 * j); }
+    };
+    int tbw, tbr, zto;
+    {
+      int c8t, g8t;
+      lane8(c8t, g8t);
+      tbw = tbase + g8t * 17 + c8t;                              // transposition tile: write [4 r + g][c]
+      tbr = tbase + c8t * 17 + g8t;                              //                     read  [c][4 kk + g]
+      zto = O_Z * 8 + c8t;                                       // Z image, T product's right operand: [pair's row][16 j + c]
+    }
+    c_quarter(0);
+    PAIR_SB();
+    PSTAMP(11);
+    double at[4], zra[QT], zrb[QT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) LDSD(tbw + r * (4 * 17 * 8)) = w[0][r];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) at[kk] = LDSD(tbr + kk * 32);
+    t_reads(zto, 0, 0, zra, zrb);
+    PAIR_SB();
+    PSTAMP(12);
+    c_quarter(1);
+    c_quarter(2);
+    c_quarter(3);
+    PAIR_SB();
     PSTAMP(3);
     if (role1) {
       PAIR_BARRIER();                        // B_s for waves 4-7: between the C and the T product
@@ -326,40 +436,55 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       after_barrier(s);
       PSTAMP(6);
     }
-    // T[16 rows x 16 q] += w (z z)^T   (K = the tile's 16 pairs; the weights transposed through the wave's LDS tile, the tile's
-    // 8 x QT z values read in one batch)
+    // ======== T(s): T[16 rows x 16 q] += w (z z)^T, K = a tile's 16 pairs, one k-step (four pairs) at a time; the operands of the
+    // next k-step (and, three k-steps into a tile, the next tile's transposed weights) are requested before the current one is
+    // issued ========
     d4 Tacc[QT];
 #pragma unroll
     for (int j = 0; j < QT; ++j) Tacc[j] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
+      double atn[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tb[(4 * r + g) * 17 + c] = w[k][r];
-      wave_lds_fence();
-      double at[4];
+      for (int kk = 0; kk < 4; ++kk) {
+        double zna[QT], znb[QT];
+        const bool last = (k == NT - 1 && kk == 3);
+        if (kk == 2 && k + 1 < NT) {           // the tile's own transposed weights are in registers: the tile may be overwritten
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) at[kk] = tb[c * 17 + 4 * kk + g];
-      wave_lds_fence();
+          for (int r = 0; r < 4; ++r) LDSD(tbw + r * (4 * 17 * 8)) = w[k + 1][r];
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        double zz[2][QT];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int pk = (pkt[k][h2] >> (16 * kk)) & 0xffff;
-          const int pa = pk & 0xff, pb = pk >> 8;
-#pragma unroll
-          for (int j = 0; j < QT; ++j) zz[kk][j] = Zl[pa * ZS + 16 * j + c] * Zl[pb * ZS + 16 * j + c];
+          for (int k2 = 0; k2 < 4; ++k2) atn[k2] = LDSD(tbr + k2 * 32);
         }
+        if (kk < 3) t_reads(zto, k, kk + 1, zna, znb);
+        else if (!last) t_reads(zto, k + 1, 0, zna, znb);
+        double zz[QT];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int j = 0; j < QT; ++j) zz[j] = zra[j] * zrb[j];
+        PAIR_SB();
 #pragma unroll
-          for (int j = 0; j < QT; ++j) Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[2 * h2 + kk], zz[kk][j], Tacc[j], 0, 0, 0);
+        for (int j = 0; j < QT; ++j) Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], zz[j], Tacc[j], 0, 0, 0);
+        PAIR_SB();
+        if (!last) {
+#pragma unroll
+          for (int j = 0; j < QT; ++j) { zra[j] = zna[j]; zrb[j] = znb[j]; }
+        }
       }
+      if (k + 1 < NT) {
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) at[k2] = atn[k2];
+      }
+      PSTAMP(7 + k);
     }
+    {
+      int c8f, g8f;
+      lane8(c8f, g8f);
+      int tB = tBs + g8f * TT + c8f;                             // this lane's corner: [4 r + g][16 j + c]
+      asm volatile("" : "+v"(tB));
 #pragma unroll
-    for (int j = 0; j < QT; ++j)
+      for (int j = 0; j < QT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&ttile[(4 * r + g) * TT + 16 * j + c], Tacc[j][r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(LDSP(tB + (4 * r * TT + 16 * j) * 8), Tacc[j][r]);
+    }
     PSTAMP(4);
     if (!role1) {
       PAIR_BARRIER();                        // B_s for waves 0-3
@@ -367,6 +492,12 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       after_barrier(s);
       PSTAMP(6);
     }
+#ifdef PAIR_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sq_[0]), "+s"(sq_[1]), "+s"(sq_[2]), "+s"(sq_[3]), "+s"(sq_[4]), "+s"(sq_[5]), "+s"(sq_[6]),
+                 "+s"(sq_[7]), "+s"(sq_[8]), "+s"(sq_[9]), "+s"(sq_[10]), "+s"(sq_[11]), "+s"(sq_[12]));
+    for (int i = 0; i < 13; ++i) st_[i] += (long long)(sq_[i] - sprev_);         // offsets from the step's start
+    sprev_ = role1 ? sq_[4] : sq_[6];
+#endif
   }
   // role 1's T adds of the last step came after the last barrier: one more, then the last T tile leaves
   PAIR_BARRIER();
@@ -374,8 +505,8 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 
 #ifdef PAIR_STAMPS
   if (a.dbg && lane == 0) {
-    st_[7] = nsteps;
-    for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = (double)st_[i];
+    st_[15] = nsteps;
+    for (int i = 0; i < 16; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = (double)st_[i];
   }
 #endif
   // ---- flush: C partial of this (row range, pair group), pair sums of psi2
@@ -389,9 +520,10 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       for (int r = 0; r < 4; ++r)
         if (q < QP) a.Cpart[((size_t)rr * a.Ppad + 16 * tau + 4 * r + g) * QP + q] = Cacc[k][j][r];
     }
-    const double ps = psw[16 * k];
-    if (g == 0 && ((pkn[k] >> 16) & 1)) {
-      const int pa = pkn[k] & 0xff, pb = (pkn[k] >> 8) & 0xff;
+    const double ps = LDSD(kpo + pso_d + 128 * k);
+    if (g == 0 && ((pvalid >> k) & 1)) {
+      int pa, pb;
+      pair_ab(16 * tau + c, M, a.P, pa, pb);
       const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
       a.p2_part[(size_t)rr * a.tri + hi * (hi + 1) / 2 + lo] = ps;
     }
@@ -439,7 +571,7 @@ __global__ void __launch_bounds__(256) psi2_pair_prep_kernel(const int64_t N, co
     __syncthreads();
     for (int i = t; i < 16 * TS; i += 256) {
       const int row = i / TS, q = i - row * TS;
-      r[i] = (q < QP) ? dd[row * QP + q].x : 0.0;
+      r[i] = (q < QP) ? -0.5 * dd[row * QP + q].x : 0.0;          // -d2 / 2: the Gram product then yields the exponent itself
     }
 #pragma unroll 1
     for (int rw = rh * 8; rw < rh * 8 + 8; ++rw) {
@@ -615,20 +747,19 @@ __global__ void __launch_bounds__(256) psi2_pair_dz3_kernel(const int M, const i
     const double cv = Csum[(size_t)p * QP + q];
     s += Zc[(size_t)mp * QP + q] * (mp == m ? cv : 0.5 * cv);
   }
-  slab[q * RGP_PSI2_TEAM + m] = -s;
+  slab[q * RGP_PSI2_TEAM + m] = 2.0 * s;                  // the C sums were taken over -d2 / 2
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-static int pair_hs(int M) { return M <= 16 ? 16 : ((M - 16 + 31) / 32) * 32 + 16; }      // >= M, = 16 mod 32 (bank spread of the four row groups)
 
 bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   if (M < 2 || M > 112 || QP < 8 || QP > RGP_MAX_QP || (QP & 3) || N < 1) return false;
   g.M = M; g.QP = QP;
   g.QT = (QP + 15) / 16;
   g.TS = 16 * g.QT + 1;
-  g.HS = pair_hs(M);
+  g.HS = PAIR_HS;
   g.OS = ((16 * g.QT) % 32 == 16) ? 16 * g.QT : 16 * g.QT + 16;      // row stride of the T tiles (= 16 mod 32)
   g.RS = (16 * (g.TS + g.HS) + 127) / 128 * 128;                       // record length: whole 1-KiB pieces
   g.M2 = (M + 1) & ~1;
@@ -644,8 +775,8 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int64_t nb = 2 * (int64_t)h->num_cu;
   if (nb > g.ntiles) nb = g.ntiles;
   g.NB = (int)nb;
-  const size_t zs = (size_t)(M * g.TS + 127) & ~(size_t)127;
-  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.HS + 3 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17 + 2 * PAIR_GROUP) * sizeof(double);
+  const size_t zs = (size_t)M * g.TS;
+  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.HS + 3 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17 + 3 * PAIR_GROUP) * sizeof(double);
   return g.lds <= 160 * 1024;
 }
 
@@ -681,27 +812,30 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3(prep_grid), dim3(256), 0, s, N, g.ntiles, M, g.HS, g.RS, zt.Zc, zt.lam, rt.Xmu,
                      rt.d2, rt.g0, rec, PV, g.PW);
   PairArgs a{};
-  a.N = N; a.ntiles = g.ntiles; a.M = M; a.P = g.P; a.G = g.G; a.RR = g.RR; a.HS = g.HS; a.RSP = g.RS; a.PW = g.PW; a.M2 = g.M2;
+  a.N = N; a.ntiles = g.ntiles; a.M = M; a.P = g.P; a.G = g.G; a.RR = g.RR; a.PW = g.PW; a.M2 = g.M2;
   a.tri = M * (M + 1) / 2; a.Ppad = g.Ppad;
   a.rec = rec; a.Zc = zt.Zc; a.lam = zt.lam; a.dLs = dLs; a.PV = PV; a.Cpart = Cpart; a.p2_part = o.p2_part;
   hipError_t e = hipFuncSetAttribute((const void*)psi2_pair_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
   if (e != hipSuccess) return e;
 #ifdef PAIR_STAMPS
   static double* dbg_s = nullptr;
-  if (!dbg_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbg_s, 256 * 8 * 8 * sizeof(double));
+  if (!dbg_s && getenv("RGP_STAMPS")) (void)hipMalloc(&dbg_s, 256 * 8 * 16 * sizeof(double));
   a.dbg = dbg_s;
 #endif
   hipLaunchKernelGGL((psi2_pair_kernel<QP>), dim3(g.G * g.RR), dim3(512), g.lds, s, a);
 #ifdef PAIR_STAMPS
   if (dbg_s && g.G * g.RR <= 256) {
     (void)hipStreamSynchronize(s);
-    static double hb[256 * 8 * 8];
+    static double hb[256 * 8 * 16];
     (void)hipMemcpy(hb, dbg_s, sizeof(hb), hipMemcpyDeviceToHost);
-    double acc[8] = {0};
-    const int nw = g.G * g.RR * 8;
-    for (int w = 0; w < nw; ++w) for (int i = 0; i < 7; ++i) acc[i] += hb[w * 8 + i] / (hb[w * 8 + 7] > 0 ? hb[w * 8 + 7] : 1) / nw;
-    fprintf(stderr, "pair QP=%d steps/wg %.0f cycles/step (mean over waves): h-init %.0f gram %.0f exp+v2 %.0f C %.0f T %.0f barrier-wait %.0f after-barrier %.0f\n", QP,
-            hb[7], acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6]);
+    const int nwg = g.G * g.RR;
+    for (int role = 0; role < 2; ++role) {
+      double acc[16] = {0};
+      for (int wg = 0; wg < nwg; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int i = 0; i < 13; ++i)
+        acc[i] += hb[(wg * 8 + w) * 16 + i] / (hb[(wg * 8 + w) * 16 + 15] > 0 ? hb[(wg * 8 + w) * 16 + 15] : 1) / (4 * nwg);
+      fprintf(stderr, "pair QP=%d role %d steps/wg %.0f, cycles from the step's start: head %.0f gram %.0f exp+v2 %.0f | C quarter %.0f T prologue %.0f C %.0f | T tiles %.0f %.0f %.0f %.0f flush %.0f | barrier %.0f after %.0f\n", QP,
+              role, hb[15], acc[0], acc[1], acc[2], acc[11], acc[12], acc[3], acc[7], acc[8], acc[9], acc[10], acc[4], acc[5], acc[6]);
+    }
   }
 #endif
   // row gradients, dinv_l / weight-sum partials, B slabs
