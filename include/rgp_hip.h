@@ -133,7 +133,8 @@ int        rgp_side_streams_independent(rgp_handle h);
 
 /* ---- the fused layer step (replaces Layer.parameters_changed / Layer_new.update_layer + update_latent_gradients,
  *      autoreg/layers.py:1483-1488, :617-621, :1433-1450) ------------------------------------------------------
- * Sizes (Q = X_win*X_dim + U_win*U_dim; RGP_ERR_BAD_ARG beyond): D <= 64;
+ * Sizes (Q = X_win*X_dim + U_win*U_dim; RGP_ERR_BAD_ARG beyond): 1 <= D <= 2048 (the fused SVI step for
+ *   M <= 128 accepts more; the tests go up to D = 64);
  *   M <= 128,  Q <= 64  : both modes, fused kernels, side-stream pipelining (rgp_layer_prepare);
  *   M <= 1024, Q <= 64  : both modes, blocked kernels (steps run whole on the handle's stream; rgp_layer_prepare is a no-op);
  *   M <= 1024, Q <= 1024: both modes, the psi2 term as large fp64 matrix products over the pairs of inducing rows (likewise;
@@ -183,8 +184,9 @@ rgp_status rgp_kuu(rgp_handle h, int M, int Q, const double* Z, const double* va
 /* kern.psi1(Z, q(X)) -> N x M and kern.psi2(Z, q(X)) -> M x M (vardtc.py:60-61); either output may be NULL. */
 rgp_status rgp_psi_forward(rgp_handle h, int64_t N, int M, int Q, const double* mu, const double* S, const double* Z,
                            const double* variance, const double* inv_l, double* psi1, double* psi2);
-/* rgp_psi_forward for callers that cannot allocate.  It has NO counterpart in the reference: it exists for code under HIP
- * graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and the same results
+/* rgp_psi_forward for callers that cannot allocate.  It has NO counterpart in the reference: it exists for callers
+ * that cannot allocate, such as tight serving loops and harnesses that forbid hipMalloc (it has not been exercised under HIP
+ * graph capture: it waits on events of the library's side streams and sets a kernel attribute).  Same arguments, same kernels and the same results
  * (to rounding: the psi2 partial sums are combined over fewer workgroups) as rgp_psi_forward, but it calls no hipMalloc /
  * hipFree or any other allocating routine: its scratch (Z terms, row terms, partial sums) is a 20 MB static device array
  * that every GPU the library runs on holds until the process ends.  Limits: N <= 4096, M <= 128, Q <= 64; larger problems

@@ -47,10 +47,12 @@ struct BigPlan {
   int NP, fwd_tasks, fwd_chunks;         // forward: columns per wave, wave tasks, row chunks
   int sk;                                // K splits of the products that sum over the data rows
   int rows_blk;                          // workgroups of the row-gradient kernels
+  int num_cu;                            // compute units of the device the plan was made for
 };
 
 static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
   BigPlan p{};
+  p.num_cu = h->num_cu;
   p.QP = rgp_qp(Q);
   p.W = 2 * p.QP + 8;
   p.Mld = round_up(M, 64);
@@ -92,7 +94,7 @@ struct WqWs {                 // what the wide-window psi2 term needs beyond the
   int64_t nc;                 // data rows per chunk
 };
 
-static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q) {
+static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q, int num_cu) {
   const int P = M * (M + 1) / 2;
   Q.P = P;
   Q.rb = (7680 - WQ_RB_MAX) / (2 * M);
@@ -105,9 +107,10 @@ static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q)
   Q.nc = nc;
   const int64_t nexp = (nc + Q.rb - 1) / Q.rb;
   const int tiles = ((P + 127) / 128) * ((p.QP + 127) / 128);  // 128 x 128 output tiles of the row-split product C
-  // row splits of C: 1024 to 3072 workgroups of equal length, the count that leaves the fewest of the chip's 512 workgroup
-  // slots (256 CUs x 2) idle in the last round
+  // row splits of C: 1024 to 3072 workgroups of equal length, the count that leaves the fewest of the chip's workgroup
+  // slots (two per CU) idle in the last round
   Q.nsplit = 1;
+  const int slots = 2 * (num_cu > 0 ? num_cu : 256);
   if (tiles < 2048) {
     double best = 0.0;
     int lo = (1024 + tiles - 1) / tiles, hi = (3072 + tiles - 1) / tiles;
@@ -115,7 +118,7 @@ static size_t wq_carve(WsAlloc& ws, const BigPlan& p, int64_t N, int M, WqWs& Q)
     if (hi > 32) hi = 32;
     for (int ns = lo; ns <= hi; ++ns) {
       const int w = tiles * ns;
-      const double fill = (double)w / (512.0 * ((w + 511) / 512));
+      const double fill = (double)w / ((double)slots * ((w + slots - 1) / slots));
       if (fill > best + 1e-9) { best = fill; Q.nsplit = ns; }
     }
   }
@@ -172,9 +175,14 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.gmu = ws.take<double>(nq); L.gS = ws.take<double>(nq);
   L.Ym = ws.take<double>(nd); L.Yv = ws.take<double>(nd); L.dYm = ws.take<double>(nd);
   L.S12 = ws.take<double>((size_t)N * p.W);
-  L.p2_part = ws.take<double>((size_t)p.fwd_chunks * mm);
-  L.RP = ws.take<double>((size_t)p.nI * N * (2 * QP + 2));
-  L.dz2_part = ws.take<double>((size_t)p.bwd_grid * QP * p.Mld); L.dz2 = ws.take<double>((size_t)QP * p.Mld);
+  L.wide = QP > RGP_MAX_QP;
+  L.p2_part = L.RP = L.dz2_part = nullptr;
+  if (!L.wide) {                       // buffers of the blocked sweeps; the wide-window forms (wq_carve) never touch them
+    L.p2_part = ws.take<double>((size_t)p.fwd_chunks * mm);
+    L.RP = ws.take<double>((size_t)p.nI * N * (2 * QP + 2));
+    L.dz2_part = ws.take<double>((size_t)p.bwd_grid * QP * p.Mld);
+  }
+  L.dz2 = ws.take<double>((size_t)QP * p.Mld);
   L.dlam2_part = ws.take<double>((size_t)p.rows_blk * QP); L.dlam2 = ws.take<double>(QP);
   L.wsum2_part = ws.take<double>(p.rows_blk); L.wsum2 = ws.take<double>(1);
   L.dzA_part = ws.take<double>((size_t)p.sk * M * QP); L.dzA1 = ws.take<double>((size_t)M * QP); L.dzA2 = ws.take<double>((size_t)M * QP);
@@ -186,9 +194,10 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
   L.psi0sum = ws.take<double>(1); L.psi0coef = ws.take<double>(1); L.elbo_part = ws.take<double>(LAT_BLOCKS);
   L.fin_dlrow = ws.take<double>((size_t)M * QP); L.fin_gsum = ws.take<double>(M);
   L.row_off = ws.take<int64_t>(n_seq + 1); L.own_pre = ws.take<int64_t>(n_seq + 1); L.up_pre = ws.take<int64_t>(n_seq + 1);
-  L.wide = QP > RGP_MAX_QP;
-  if (L.wide) wq_carve(ws, p, N, M, L.wq);
-  {
+  if (L.wide) wq_carve(ws, p, N, M, L.wq, p.num_cu);
+  L.fp2_part = nullptr; L.frs = 1;
+  if (!L.wide && (base == nullptr || getenv("RGP_PSI2_FWD_MFMA") != nullptr)) {     // sizing passes count it: an upper bound
+
     const int nb = (M + 31) / 32, blocks = nb * (nb + 1) / 2;      // 32 x 32 pair blocks of the matrix-pipe forward kernel
     int64_t rs = (1536 + blocks - 1) / blocks;
     if (rs > (N + 63) / 64) rs = (N + 63) / 64;
@@ -1016,7 +1025,7 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
   if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
-  if (D < 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be positive");
+  if (D < 1 || D > 2048) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be between 1 and 2048");
   const BigPlan p = big_plan(h, N, M, Q);
   const int QP = p.QP;
   BigWs L;
@@ -1171,7 +1180,7 @@ static rgp_status big_vardtc_layer_step(rgp_handle h, const rgp_layer_in* in, co
   if (st) return st;
   if (in->y_uncertain && (in->X_dim != D || !in->own_var)) return rgp_fail(h, RGP_ERR_BAD_ARG, "hidden layer needs X_dim == D and own_var");
   if (!in->y_uncertain && in->X_win != 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "observed layer must have X_win == 0 (as in the reference)");
-  if (D < 1) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be positive");
+  if (D < 1 || D > 2048) return rgp_fail(h, RGP_ERR_BAD_ARG, "D must be between 1 and 2048");
   const BigPlan p = big_plan(h, N, M, Q);
   const int QP = p.QP;
   BigWs L;

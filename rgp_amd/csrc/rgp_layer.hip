@@ -100,8 +100,8 @@ __global__ void __launch_bounds__(64) stream_probe_spin_kernel(long long ticks) 
 }
 __global__ void __launch_bounds__(64) stream_probe_noop_kernel() {}
 
-static bool streams_run_side_by_side(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec) {
-  hipLaunchKernelGGL(stream_probe_spin_kernel, dim3(1), dim3(64), 0, busy, 30000LL);      // ~300 us
+static bool streams_run_side_by_side_once(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec, long long ticks) {
+  hipLaunchKernelGGL(stream_probe_spin_kernel, dim3(1), dim3(64), 0, busy, ticks);
   (void)hipEventRecord(eb, busy);
   hipLaunchKernelGGL(stream_probe_noop_kernel, dim3(1), dim3(64), 0, cand);
   (void)hipEventRecord(ec, cand);
@@ -110,6 +110,12 @@ static bool streams_run_side_by_side(hipStream_t busy, hipStream_t cand, hipEven
   (void)hipGetLastError();                              // hipErrorNotReady is sticky for hipGetLastError
   (void)hipEventSynchronize(eb);
   return side_by_side;
+}
+// ~300 us of spin; a candidate that fails is tried once more against ~3 ms before it is discarded: on a GPU shared with
+// other processes the no-op kernel of a good candidate can be late, while one that shares the busy stream's hardware queue
+// fails at any length.
+static bool streams_run_side_by_side(hipStream_t busy, hipStream_t cand, hipEvent_t eb, hipEvent_t ec) {
+  return streams_run_side_by_side_once(busy, cand, eb, ec, 30000LL) || streams_run_side_by_side_once(busy, cand, eb, ec, 300000LL);
 }
 
 // Fills side[0..2]; returns how many of them passed the test against the main stream and each other (3 = all).
@@ -137,9 +143,12 @@ static int pick_side_streams(hipStream_t main_stream, hipStream_t side[3]) {
   while (n_rej > 0) (void)hipStreamDestroy(rejected[--n_rej]);
   (void)hipEventDestroy(eb);
   (void)hipEventDestroy(ec);
-  return n_ok == 3 ? passed : -1;
+  if (n_ok == 3) return passed;
+  while (n_ok > 0) { (void)hipStreamDestroy(side[--n_ok]); side[n_ok] = nullptr; }     // could not create three streams at all
+  return -1;
 }
 
+extern "C" void rgp_destroy(rgp_handle h);
 extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) {
   if (!out) return RGP_ERR_BAD_ARG;
   rgp_ctx* h = new rgp_ctx();
@@ -148,14 +157,14 @@ extern "C" rgp_status rgp_create(rgp_handle* out, int device, void* hip_stream) 
   if (hipSetDevice(device) != hipSuccess) { delete h; return RGP_ERR_HIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
-  if (static_scratch_lookup(device, &h->static_scratch) != hipSuccess) { delete h; return RGP_ERR_HIP; }
-  if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { delete h; return RGP_ERR_HIP; }
+  if (static_scratch_lookup(device, &h->static_scratch) != hipSuccess) { rgp_destroy(h); return RGP_ERR_HIP; }
+  if (hipMalloc((void**)&h->status, 2 * sizeof(int)) != hipSuccess) { h->status = nullptr; rgp_destroy(h); return RGP_ERR_HIP; }
   hipMemsetAsync(h->status, 0, 2 * sizeof(int), h->stream);
   h->overlap = getenv("RGP_NO_OVERLAP") == nullptr;
   {
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     h->side_streams_independent = pick_side_streams(h->stream, side);
-    if (h->side_streams_independent < 0) { delete h; return RGP_ERR_HIP; }
+    if (h->side_streams_independent < 0) { rgp_destroy(h); return RGP_ERR_HIP; }      // frees the status words too
     h->side_pre = side[0]; h->side_post = side[1]; h->side_rows = side[2];
   }
   hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming);
@@ -187,6 +196,14 @@ extern "C" void rgp_destroy(rgp_handle h) {
   if (h->ws) hipFree(h->ws);
   for (int k = 0; k < rgp_ctx::NSLOT; ++k) if (h->ws_slot[k]) hipFree(h->ws_slot[k]);
   if (h->status) hipFree(h->status);
+  hipEvent_t single[] = {h->ev_main, h->ev_post_pos, h->ev_post_tail, h->ev_prep, h->ev_stats};
+  for (hipEvent_t e : single) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < rgp_ctx::NSLOT; ++k) {
+    hipEvent_t slot[] = {h->ev_pre[k], h->ev_pre_a[k], h->ev_rows[k], h->ev_yry[k], h->ev_prepz[k], h->ev_pre_b[k], h->ev_slot_main[k],
+                         h->ev_done[k]};
+    for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
+  }
+  for (auto& pe : h->prof_events) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
   delete h;
 }
 

@@ -18,8 +18,15 @@ static __device__ __forceinline__ double fma_rrr(double a, double b, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// max(x, -800) that keeps a NaN: one unsigned minimum on the high word (x < -800 exactly when that word, read as unsigned,
+// exceeds the high word of -800.0).  fmax would return -800 for a NaN and the exponential would turn a bad input into 0.
+// The arithmetic NaNs of the device and numpy's nan have the sign bit clear, which is what the comparison relies on.
+static __device__ __forceinline__ double clamp_exp_arg(double x) {
+  const unsigned hi = (unsigned)__double2hiint(x);
+  return __hiloint2double((int)(hi < 0xC0890000u ? hi : 0xC0890000u), __double2loint(x));
+}
 static __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T) {
-  x = fmax(x, -800.0);                                              // also maps -inf; the result underflows to 0
+  x = clamp_exp_arg(x);                                             // also maps -inf; the result underflows to 0
   const double t = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);          // 256/ln2; integer n in the low mantissa bits
   const int n = __double2loint(t);
   const double nf = t - 0x1.8p52;

@@ -45,7 +45,7 @@ static __device__ __forceinline__ void wave_lds_fence() {
 
 // exp_tab with a NaN-preserving clamp
 static __device__ __forceinline__ double exp_tab_n(double x, const double* __restrict__ T) {
-  x = (x < -800.0) ? -800.0 : x;
+  x = clamp_exp_arg(x);
   const double t = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);
   const int n = __double2loint(t);
   const double nf = t - 0x1.8p52;
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double x = acc[k][r];
-          x = (x < -800.0) ? -800.0 : x;                                     // NaN stays NaN
+          x = clamp_exp_arg(x);                                              // NaN stays NaN
           const double tt = fma(x, 0x1.71547652b82fep+8, 0x1.8p52);
           const int n = __double2loint(tt);
           const double nf = tt - 0x1.8p52;

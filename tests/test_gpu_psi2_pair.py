@@ -84,14 +84,22 @@ def test_many_steps_per_workgroup_and_minibatch():
     compare(o, g, seqs=[0, 2])
 
 
-def test_nan_input_reaches_the_psi2_gradients(HP):
-    """A NaN in one window mean is not dropped by the exponential's clamp: the gradients of that row come out NaN."""
+@pytest.mark.parametrize('mode', [0, 2])
+def test_nan_input_reaches_psi2_and_its_gradients(HP, mode):
+    """A NaN in one window mean is not dropped by the exponential's clamp, in the sweep kernels (mode 0) and in the pair form
+    (mode 2): psi2 and the gradients of that row come out NaN."""
     H = HP
+    H.set_psi2_pair(mode)
     N, M, Q = 40, 20, 8
     mu, S, Z, var, il = make(N, M, Q, 3)
     mu[7, 2] = np.nan
     w2 = np.random.default_rng(1).standard_normal((M, M))
-    g = H.psi_backward(dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il), 0.0, None, dev(H, w2))
+    args = (dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il))
+    _, p2 = H.psi_forward(*args)
+    g = H.psi_backward(*args, 0.0, None, dev(H, w2))
     H.sync()
+    H.set_psi2_pair(2)
+    assert np.isnan(p2.cpu().numpy()).all()
     assert np.isnan(g['dmu'].cpu().numpy()[7]).all()
     assert np.isnan(g['dZ'].cpu().numpy()).any()
+    assert np.isfinite(g['dmu'].cpu().numpy()[:7]).all()

@@ -1,6 +1,6 @@
 """rgp_psi_forward_static (the entry point that allocates nothing: its scratch is a static device array) against
 rgp_psi_forward through the C ABI: two calls in a row on the same GPU, the second with a smaller input, so stale scratch
-contents of the first call would show.  fp64, same kernels, partial sums combined over fewer workgroups: 1e-13 relative."""
+contents of the first call would show; the device's free memory is the same before and after a call.  fp64, same kernels, partial sums combined over fewer workgroups: 1e-13 relative."""
 import numpy as np
 import pytest
 
@@ -22,8 +22,16 @@ def test_static_scratch_entry_point_matches_the_allocating_one():
         want1, want2 = H.psi_forward(mu, S, Z, var, il)
         got1 = torch.full((N, M), float('nan'), dtype=torch.float64, device=H.device)
         got2 = torch.full((M, M), float('nan'), dtype=torch.float64, device=H.device)
+        H.psi_forward_static(mu, S, Z, var, il, got1, got2)       # the first call at a shape may load code objects
+        H.sync()
+        torch.cuda.synchronize()
+        free0, reserved0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+        got1.fill_(float('nan')); got2.fill_(float('nan'))
         H.psi_forward_static(mu, S, Z, var, il, got1, got2)
         H.sync()
+        torch.cuda.synchronize()
+        # what the entry point is for: the call took no device memory, neither through the library nor through torch
+        assert torch.cuda.mem_get_info()[0] == free0 and torch.cuda.memory_reserved() == reserved0
         assert torch.equal(got1, want1)                           # psi1: same kernel, no reduction
         err = float((got2 - want2).abs().max() / want2.abs().max())
         assert err <= 1e-13, (N, M, Q, err)
