@@ -531,202 +531,251 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Input records of the main kernel, one per tile of 16 data rows: [d2 16 x TS (zero padded) | h' 16 x HS].
-// Thread = (inducing row m, half of the tile's rows); the tile's d2 and d2 mu rows are staged in LDS and broadcast.
-// Rows beyond N get d2 = 0 and h' = -inf (their exponentials are 0).
+// Input records of the main kernel, one per tile of 16 data rows: [-d2 / 2, 16 x TS (zero padded) | h' 16 x HS] with
+//   h'[n,m] = sum_q (d2 mu)[n,q] z[m,q] - 1/4 sum_q d2[n,q] z[m,q]^2 - 1/4 sum_q lam_q z[m,q]^2 + g0[n] / 2,
+// a [16 x 2 QP] x [2 QP x M] product on the matrix pipe: wave = one tile of rows, left operands (d2 mu | d2) straight from
+// global memory into registers, right operands (z | -z^2 / 4) from two LDS images of Z.  Rows beyond N get d2 = 0 and
+// h' = -inf (their exponentials are 0).  The kernel also zeroes the tile's rows of the buffer the pair groups add into.
 // ------------------------------------------------------------------------------------------------------------------
 template <int QP>
-__global__ void __launch_bounds__(256) psi2_pair_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int HS, const int RS,
-                                                              const double* __restrict__ Zc, const double* __restrict__ lam,
-                                                              const double* __restrict__ Xmu, const double* __restrict__ d2,
-                                                              const double* __restrict__ g0, double* __restrict__ rec,
-                                                              double* __restrict__ PV, const int PW) {
-  constexpr int QT = (QP + 15) / 16, TS = 16 * QT + 1;
-  __shared__ __attribute__((aligned(16))) double2 dd[16 * QP];          // (d2, d2 mu)
-  __shared__ double gs[16];
-  const int t = threadIdx.x, m = t & 127, rh = t >> 7;
-  const bool act = m < M;
-  double z[QP];
-  double ellq = 0.0;
-#pragma unroll
-  for (int q = 0; q < QP; ++q) {
-    z[q] = act ? Zc[(size_t)m * QP + q] : 0.0;
-    ellq += 0.25 * lam[q] * z[q] * z[q];
+__global__ void __launch_bounds__(256, 2) psi2_pair_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int HS, const int RS,
+                                                                 const double* __restrict__ Zc, const double* __restrict__ lam,
+                                                                 const double* __restrict__ Xmu, const double* __restrict__ d2,
+                                                                 const double* __restrict__ g0, double* __restrict__ rec,
+                                                                 double* __restrict__ PV, const int PW) {
+  constexpr int QT = (QP + 15) / 16, TS = 16 * QT + 1, ZQ = QP + 1, KQ = QP / 4;
+  extern __shared__ double sm[];
+  const int MT = (M + 15) >> 4;
+  double* const Zs = sm;                          // [16 MT][ZQ]   z
+  double* const Z2s = Zs + 16 * MT * ZQ;          // [16 MT][ZQ]   -z^2 / 4
+  double* const el = Z2s + 16 * MT * ZQ;          // [16 MT]       1/4 sum_q lam z^2
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 16 * MT * ZQ; i += 256) {
+    const int m = i / ZQ, q = i - m * ZQ;
+    const double z = (m < M && q < QP) ? Zc[(size_t)m * QP + q] : 0.0;
+    Zs[i] = z;
+    Z2s[i] = -0.25 * z * z;
   }
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();
+  for (int m = t; m < 16 * MT; m += 256) {
+    double e = 0.0;
+    for (int q = 0; q < QP; ++q) e -= lam[q] * Z2s[m * ZQ + q];
+    el[m] = e;
+  }
+  __syncthreads();
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t n0 = tile * 16;
     double* const r = rec + (size_t)tile * RS;
     {                                                      // the pair groups ADD their sums over pairs into this tile's rows
       const int64_t lim = (N - n0 < 16 ? N - n0 : 16) * PW;
-      for (int i = t; i < lim; i += 256) PV[n0 * PW + i] = 0.0;
+      for (int i = lane; i < lim; i += 64) PV[n0 * PW + i] = 0.0;
     }
-    __syncthreads();
-    for (int i = t; i < 16 * QP; i += 256) {
-      const int row = i / QP;
-      const bool ok = n0 + row < N;
-      const double dv = ok ? d2[n0 * QP + i] : 0.0, mv = ok ? Xmu[n0 * QP + i] : 0.0;
-      dd[i] = make_double2(dv, dv * mv);
-    }
-    if (t < 16) gs[t] = (n0 + t < N) ? 0.5 * g0[n0 + t] : -INFINITY;
-    __syncthreads();
-    for (int i = t; i < 16 * TS; i += 256) {
-      const int row = i / TS, q = i - row * TS;
-      r[i] = (q < QP) ? -0.5 * dd[row * QP + q].x : 0.0;          // -d2 / 2: the Gram product then yields the exponent itself
-    }
-#pragma unroll 1
-    for (int rw = rh * 8; rw < rh * 8 + 8; ++rw) {
-      const double2* dr = dd + rw * QP;
-      double h0 = 0.0, h1 = 0.0;
+    // left operands of the lane: row n0 + c, columns 4 kk + g
+    double Adm[KQ], Ad[KQ];
+    {
+      const int64_t n = n0 + c;
+      const bool ok = n < N;
+      const size_t o = (size_t)(ok ? n : N - 1) * QP + g;
 #pragma unroll
-      for (int q = 0; q < QP; q += 2) {
-        const double2 x0 = dr[q], x1 = dr[q + 1];
-        h0 += z[q] * (x0.y - 0.25 * x0.x * z[q]);
-        h1 += z[q + 1] * (x1.y - 0.25 * x1.x * z[q + 1]);
+      for (int kk = 0; kk < KQ; ++kk) {
+        const double dv = ok ? d2[o + 4 * kk] : 0.0, mv = Xmu[o + 4 * kk];
+        Ad[kk] = dv;
+        Adm[kk] = dv * mv;
+        r[c * TS + 4 * kk + g] = -0.5 * dv;                // -d2 / 2: the Gram product of the main kernel then yields the exponent itself
       }
-      if (m < HS) r[16 * TS + rw * HS + m] = act ? ((h0 + h1) - ellq) + gs[rw] : 0.0;
+    }
+    for (int i = lane; i < 16 * (TS - QP); i += 64) {      // zero padding of the d2 tile
+      const int row = i / (TS - QP), col = QP + (i - row * (TS - QP));
+      r[row * TS + col] = 0.0;
+    }
+    double gs[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) gs[rr] = (n0 + 4 * rr + g < N) ? 0.5 * g0[n0 + 4 * rr + g] : -INFINITY;
+    for (int mt = 0; mt < MT; ++mt) {
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      const int zo = (16 * mt + c) * ZQ + g;
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Adm[kk], Zs[zo + 4 * kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[kk], Z2s[zo + 4 * kk], acc, 0, 0, 0);
+      }
+      const int m = 16 * mt + c;
+      const double em = el[m];
+      if (m < HS) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) r[16 * TS + (4 * rr + g) * HS + m] = (m < M) ? (acc[rr] - em) + gs[rr] : 0.0;
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Row kernel: sums the pair groups' partials of V2 and T per tile of 16 rows, then
-//   job A  (thread = (row, 16-column stripe)): [a1 | vz2 | ws] = v [Z | Z^2 | 1] and the row gradients, dinv_l and sum-of-weights
-//           partials;   job B (thread = (inducing row, half of the columns)): B1 += v^T (d2 mu), B2 += v^T d2 in registers over
-//           the workgroup's tiles; at the end the slab dz[q][m] = 2 B1 - z B2.
+// Row kernel, on the matrix pipe.  A workgroup walks super-tiles of 32 data rows; v = V2 / 2 and (d2 mu | d2) of the
+// super-tile are staged in LDS.
+//   job B  (wave w owns the inducing-row tiles w and w + 4): [B1 | B2] += v^T (d2 mu | d2), accumulated in registers over all
+//           the workgroup's super-tiles; at the end the slab dz[q][m] = 2 B1 - z B2.
+//   job A  (wave = (tile of 16 rows, Z or Z^2)): a1 = v Z or vz2 = v Z^2, right operands from global memory (Z is small
+//           and cached), the row sums of v on the way; the results go to LDS over the (d2 mu | d2) image.
+//   epilogue (thread = (window column, every RPP-th row)): the row gradients from a1, vz2, T and the row sums, dinv_l and
+//           sum-of-weights partials.
 // ------------------------------------------------------------------------------------------------------------------
 template <int QP>
-__global__ void __launch_bounds__(256) psi2_pair_rows_kernel(const int64_t N, const int64_t ntiles, const int M, const int Q,
-                                                              const int G, const int PW, const int M2,
-                                                              const double* __restrict__ PV, const double* __restrict__ Zc,
-                                                              const double* __restrict__ lam, const double* __restrict__ Xmu,
-                                                              const double* __restrict__ d2, double* __restrict__ gmu,
-                                                              double* __restrict__ gS, const int accumulate,
-                                                              double* __restrict__ dz_part, double* __restrict__ dlam_part,
-                                                              double* __restrict__ wsum_part) {
-  constexpr int QT = (QP + 15) / 16, QH = QP / 2, ZQ = QP + 1;
+__global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N, const int M, const int Q, const int PW, const int M2,
+                                                                 const double* __restrict__ PV, const double* __restrict__ Zc,
+                                                                 const double* __restrict__ lam, const double* __restrict__ Xmu,
+                                                                 const double* __restrict__ d2, double* __restrict__ gmu,
+                                                                 double* __restrict__ gS, const int accumulate,
+                                                                 double* __restrict__ dz_part, double* __restrict__ dlam_part,
+                                                                 double* __restrict__ wsum_part) {
+  constexpr int QT = (QP + 15) / 16, CT = 2 * QT, DS = 16 * CT + 1, RPP = 256 / QP;
   extern __shared__ double sm[];
-  const int VS = M2 + 1;
-  double2* const dd = reinterpret_cast<double2*>(sm);     // [16][QP] (d2 mu, d2)
-  double* const mus = sm + 2 * 16 * QP;                   // [16][QP]
-  double* const Tt = mus + 16 * QP;                       // [16][QP]
-  double* const red = Tt + 16 * QP;                       // [16][QP] + [16]
-  double* const Zs = red + 16 * QP + 16;                  // [M][ZQ]
-  double* const vt = Zs + M * ZQ;                         // [16][VS]
-  const int t = threadIdx.x;
-  for (int i = t; i < M * QP; i += 256) { const int m = i / QP, q = i - m * QP; Zs[m * ZQ + q] = Zc[i]; }
-  // job A identity
-  const int ra = t >> 4, cq = t & 15;
-  // job B identity
-  const int mb = t & 127, qh = t >> 7;
-  const bool actb = mb < M;
-  double b1[QH], b2[QH];
+  const int MT = (M + 15) >> 4, VW = 16 * MT, VS = VW + 1, K4 = (M + 3) >> 2;
+  double* const vS = sm;                          // [32][VS]  v = V2 / 2, zero beyond M and beyond N
+  double* const dS = vS + 32 * VS;                // [32][DS]  (d2 mu | d2), each half padded to 16 QT; later (a1 | vz2)
+  double* const wsS = dS + 32 * DS;               // [32]      row sums of v
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int64_t nst = (N + 31) >> 5;
+  const bool two = w + 4 < MT;                    // this wave owns a second tile of inducing rows
+  d4 Bacc[2][CT];
 #pragma unroll
-  for (int j = 0; j < QH; ++j) { b1[j] = 0.0; b2[j] = 0.0; }
-  double dl_acc[QT], ws_acc = 0.0;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int j = 0; j < QT; ++j) dl_acc[j] = 0.0;
+    for (int j = 0; j < CT; ++j) Bacc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int eq = t % QP, er = t / QP;             // epilogue identity
+  double dl_acc = 0.0, ws_acc = 0.0;
+  const int rt = w & 1, ch = w >> 1;              // job A identity
 
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t n0 = tile * 16;
-    __syncthreads();
-    // sum of the partials: V2 / 2 and T
-    for (int i = t; i < 16 * PW; i += 256) {
-      const int row = i / PW, col = i - row * PW;
+  for (int64_t st = blockIdx.x; st < nst; st += gridDim.x) {
+    const int64_t n0 = st * 32;
+    __syncthreads();                              // the previous epilogue is done with dS and wsS
+    for (int i = t; i < 32 * VW; i += 256) {
+      const int row = i / VW, col = i - row * VW;
       const int64_t n = n0 + row;
-      double s = 0.0;
-      if (n < N)
-        for (int gg = 0; gg < G; ++gg) s += PV[((size_t)gg * N + n) * PW + col];
-      if (col < M2) vt[row * VS + col] = 0.5 * s;
-      else Tt[row * QP + (col - M2)] = s;
+      vS[row * VS + col] = (col < M2 && n < N) ? 0.5 * PV[(size_t)n * PW + col] : 0.0;
     }
-    for (int i = t; i < 16 * QP; i += 256) {
-      const int row = i / QP;
-      const bool ok = n0 + row < N;
-      const double dv = ok ? d2[n0 * QP + i] : 0.0, mv = ok ? Xmu[n0 * QP + i] : 0.0;
-      dd[i] = make_double2(dv * mv, dv);
-      mus[i] = mv;
+    for (int i = t; i < 32 * 16 * CT; i += 256) {
+      const int row = i / (16 * CT), col = i - row * (16 * CT);
+      const int half = col >= 16 * QT ? 1 : 0, qq = col - half * 16 * QT;
+      const int64_t n = n0 + row;
+      double v = 0.0;
+      if (qq < QP && n < N) {
+        const double dv = d2[(size_t)n * QP + qq];
+        v = half ? dv : dv * Xmu[(size_t)n * QP + qq];
+      }
+      dS[row * DS + col] = v;
     }
     __syncthreads();
-    // job A
-    {
-      double a1[QT], vz2[QT], ws = 0.0;
+    // ---- job B: K = the super-tile's 32 rows
+    if (w < MT) {
+#pragma unroll 2
+      for (int kk = 0; kk < 8; ++kk) {
+        const int ro = 4 * kk + g;
+        const double a0 = vS[ro * VS + 16 * w + c];
+        const double a1 = two ? vS[ro * VS + 16 * (w + 4) + c] : 0.0;
+        double b[CT];
 #pragma unroll
-      for (int j = 0; j < QT; ++j) { a1[j] = 0.0; vz2[j] = 0.0; }
-      const double* vr = vt + ra * VS;
-      for (int m = 0; m < M; ++m) {
-        const double vv = vr[m];
-        ws += vv;
+        for (int j = 0; j < CT; ++j) b[j] = dS[ro * DS + 16 * j + c];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) Bacc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[j], Bacc[0][j], 0, 0, 0);
+        if (two) {
+#pragma unroll
+          for (int j = 0; j < CT; ++j) Bacc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[j], Bacc[1][j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- job A: K = the inducing rows
+    d4 Aacc[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) Aacc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    double wsum = 0.0;
+    {
+      const double* vr = vS + (16 * rt + c) * VS + g;
+#pragma unroll 4
+      for (int kk = 0; kk < K4; ++kk) {
+        const double a = vr[4 * kk];
+        wsum += a;
+        const int m = 4 * kk + g;
+        const double* zr = Zc + (size_t)(m < M ? m : M - 1) * QP + c;
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
-          const int q = cq + 16 * j;
-          const double z = (q < QP) ? Zs[m * ZQ + q] : 0.0;
-          const double lz = vv * z;
-          a1[j] += lz;
-          vz2[j] += lz * z;
+          const double z = (16 * j + c < QP) ? zr[16 * j] : 0.0;
+          Aacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ch ? z * z : z, Aacc[j], 0, 0, 0);
         }
       }
-      const int64_t n = n0 + ra;
-#pragma unroll
-      for (int j = 0; j < QT; ++j) {
-        const int q = cq + 16 * j;
-        if (q < QP && n < N) {
-          if (q < Q) {
-            const double mu = mus[ra * QP + q], dq = dd[ra * QP + q].y;
-            const double a23 = 0.5 * (vz2[j] + Tt[ra * QP + q]);
-            const double dmu = 2.0 * dq * (a1[j] - mu * ws);
-            const double ddq = -mu * mu * ws + 2.0 * mu * a1[j] - a23 + 0.5 * ws / dq;
-            const double dS = -2.0 * dq * dq * ddq;
-            if (accumulate) { gmu[n * QP + q] += dmu; gS[n * QP + q] += dS; }
-            else { gmu[n * QP + q] = dmu; gS[n * QP + q] = dS; }
-            const double il = 1.0 / lam[q];
-            dl_acc[j] += ddq * (dq * il) * (dq * il) - 0.5 * ws * il;
-          } else if (!accumulate) {
-            gmu[n * QP + q] = 0.0; gS[n * QP + q] = 0.0;
-          }
-        }
-      }
-      if (cq == 0 && n < N) ws_acc += ws;
     }
-    // job B
-    if (actb) {
-#pragma unroll 2
-      for (int r = 0; r < 16; ++r) {
-        const double vv = vt[r * VS + mb];
-        const double2* dr = dd + r * QP + qh * QH;
+    __syncthreads();                              // every wave is done with (d2 mu | d2): job A's results take its place
 #pragma unroll
-        for (int j = 0; j < QH; ++j) {
-          const double2 x = dr[j];
-          b1[j] += vv * x.x;
-          b2[j] += vv * x.y;
+    for (int j = 0; j < QT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dS[(16 * rt + 4 * r + g) * DS + 16 * (ch * QT + j) + c] = Aacc[j][r];
+    if (ch == 0) {
+      wsum += __shfl_xor(wsum, 16);
+      wsum += __shfl_xor(wsum, 32);
+      if (g == 0) wsS[16 * rt + c] = wsum;
+    }
+    __syncthreads();
+    // ---- epilogue
+    if (er < RPP) {
+      const double il = 1.0 / lam[eq < Q ? eq : 0];
+      for (int row = er; row < 32; row += RPP) {
+        const int64_t n = n0 + row;
+        if (n >= N) break;
+        const size_t o = (size_t)n * QP + eq;
+        if (eq < Q) {
+          const double a1 = dS[row * DS + eq], vz2 = dS[row * DS + 16 * QT + eq], ws = wsS[row];
+          const double Tt = PV[(size_t)n * PW + M2 + eq], mu = Xmu[o], dq = d2[o];
+          const double a23 = 0.5 * (vz2 + Tt);
+          const double dmu = 2.0 * dq * (a1 - mu * ws);
+          const double ddq = -mu * mu * ws + 2.0 * mu * a1 - a23 + 0.5 * ws / dq;
+          const double dSv = -2.0 * dq * dq * ddq;
+          if (accumulate) { gmu[o] += dmu; gS[o] += dSv; }
+          else { gmu[o] = dmu; gS[o] = dSv; }
+          dl_acc += ddq * (dq * il) * (dq * il) - 0.5 * ws * il;
+          if (eq == 0) ws_acc += ws;
+        } else if (!accumulate) {
+          gmu[o] = 0.0; gS[o] = 0.0;
         }
       }
     }
   }
-  // slab of this workgroup: dz[q][m] = 2 B1[m,q] - z[m,q] B2[m,q]   (layout [QP][128])
+  // slab of this workgroup: dz[q][m] = 2 B1[m,q] - z[m,q] B2[m,q]   (layout [QP][128]; rows of inducing points beyond the tiles: 0)
   {
     double* slab = dz_part + (size_t)blockIdx.x * QP * RGP_PSI2_TEAM;
 #pragma unroll
-    for (int j = 0; j < QH; ++j) {
-      const int q = qh * QH + j;
-      slab[q * RGP_PSI2_TEAM + mb] = actb ? 2.0 * b1[j] - Zs[mb * ZQ + q] * b2[j] : 0.0;
+    for (int i = 0; i < 2; ++i) {
+      const int mt = w + 4 * i;
+      if (mt < MT) {
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mt + 4 * r + g, q = 16 * j + c;
+            if (q < QP) slab[q * RGP_PSI2_TEAM + m] = (m < M) ? 2.0 * Bacc[i][j][r] - Zc[(size_t)m * QP + q] * Bacc[i][j + QT][r] : 0.0;
+          }
+      }
+    }
+    const int rest = RGP_PSI2_TEAM - VW;
+    for (int i = t; i < QP * rest; i += 256) {
+      const int q = i / rest, m = VW + (i - q * rest);
+      slab[q * RGP_PSI2_TEAM + m] = 0.0;
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < QT; ++j) {
-    const int q = cq + 16 * j;
-    if (q < QP) red[ra * QP + q] = dl_acc[j];
+  if (er < RPP) {
+    dS[er * QP + eq] = dl_acc;
+    if (eq == 0) wsS[er] = ws_acc;
   }
-  if (cq == 0) red[16 * QP + ra] = ws_acc;
   __syncthreads();
   if (t < QP) {
     double s = 0.0;
-    for (int r = 0; r < 16; ++r) s += red[r * QP + t];
+    for (int r = 0; r < RPP; ++r) s += dS[r * QP + t];
     dlam_part[(size_t)blockIdx.x * QP + t] = (t < Q) ? s : 0.0;
   }
   if (t == 0) {
     double s = 0.0;
-    for (int r = 0; r < 16; ++r) s += red[16 * QP + r];
+    for (int r = 0; r < RPP; ++r) s += wsS[r];
     wsum_part[blockIdx.x] = s;
   }
 }
@@ -808,14 +857,19 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   double* Cpart = PV + r((size_t)N * g.PW);
   double* Csum = Cpart + r((size_t)g.RR * g.Ppad * g.QP);
   const int M = g.M;
-  int prep_grid = (int)(g.ntiles < 1024 ? g.ntiles : 1024);
-  hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3(prep_grid), dim3(256), 0, s, N, g.ntiles, M, g.HS, g.RS, zt.Zc, zt.lam, rt.Xmu,
-                     rt.d2, rt.g0, rec, PV, g.PW);
+  const int MT = (M + 15) / 16;
+  const size_t lp = (2 * (size_t)16 * MT * (QP + 1) + 16 * MT) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)psi2_pair_prep_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+  if (e != hipSuccess) return e;
+  int64_t prep_grid = (g.ntiles + 3) / 4;
+  if (prep_grid > 2 * (int64_t)g.NB) prep_grid = 2 * (int64_t)g.NB;
+  hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3((unsigned)prep_grid), dim3(256), lp, s, N, g.ntiles, M, g.HS, g.RS, zt.Zc, zt.lam,
+                     rt.Xmu, rt.d2, rt.g0, rec, PV, g.PW);
   PairArgs a{};
   a.N = N; a.ntiles = g.ntiles; a.M = M; a.P = g.P; a.G = g.G; a.RR = g.RR; a.PW = g.PW; a.M2 = g.M2;
   a.tri = M * (M + 1) / 2; a.Ppad = g.Ppad;
   a.rec = rec; a.Zc = zt.Zc; a.lam = zt.lam; a.dLs = dLs; a.PV = PV; a.Cpart = Cpart; a.p2_part = o.p2_part;
-  hipError_t e = hipFuncSetAttribute((const void*)psi2_pair_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+  e = hipFuncSetAttribute((const void*)psi2_pair_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
   if (e != hipSuccess) return e;
 #ifdef PAIR_STAMPS
   static double* dbg_s = nullptr;
@@ -839,11 +893,11 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   }
 #endif
   // row gradients, dinv_l / weight-sum partials, B slabs
-  const size_t lr = (5 * 16 * (size_t)QP + 16 + (size_t)M * (QP + 1) + 16 * (size_t)(g.M2 + 1)) * sizeof(double);
+  const size_t lr = (32 * (size_t)(16 * MT + 1) + 32 * (size_t)(32 * ((QP + 15) / 16) + 1) + 32) * sizeof(double);
   e = hipFuncSetAttribute((const void*)psi2_pair_rows_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, g.ntiles, M, Q, 1, g.PW, g.M2, PV, zt.Zc, zt.lam,
-                     rt.Xmu, rt.d2, o.gmu, o.gS, o.accumulate, o.dz_part, o.dlam_part, o.wsum_part);
+  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, M, Q, g.PW, g.M2, PV, zt.Zc, zt.lam, rt.Xmu, rt.d2,
+                     o.gmu, o.gS, o.accumulate, o.dz_part, o.dlam_part, o.wsum_part);
   // dZ3 from the C partials: one more slab behind the row kernel's
   launch_reduce(s, g.RR, (int64_t)g.Ppad * QP, (int64_t)g.Ppad * QP, Cpart, Csum, 1.0, 0);
   hipLaunchKernelGGL(psi2_pair_dz3_kernel, dim3((QP * RGP_PSI2_TEAM + 255) / 256), dim3(256), 0, s, M, QP, g.P, Csum, zt.Zc,
