@@ -564,27 +564,32 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_prep_kernel(const int64_t N,
     el[m] = e;
   }
   __syncthreads();
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+  // left operands of the lane: row n0 + c, columns 4 kk + g; the next tile's are requested before the current tile's products
+  double dn[KQ], mn[KQ];
+  auto fetch = [&](const int64_t tile) {
+    const int64_t n = tile * 16 + c;
+    const bool ok = n < N;
+    const size_t o = (size_t)(ok ? n : N - 1) * QP + g;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) { dn[kk] = ok ? d2[o + 4 * kk] : 0.0; mn[kk] = Xmu[o + 4 * kk]; }
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * 4 + w, tstep = (int64_t)gridDim.x * 4;
+  if (tile0 < ntiles) fetch(tile0);
+  for (int64_t tile = tile0; tile < ntiles; tile += tstep) {
     const int64_t n0 = tile * 16;
     double* const r = rec + (size_t)tile * RS;
     {                                                      // the pair groups ADD their sums over pairs into this tile's rows
       const int64_t lim = (N - n0 < 16 ? N - n0 : 16) * PW;
       for (int i = lane; i < lim; i += 64) PV[n0 * PW + i] = 0.0;
     }
-    // left operands of the lane: row n0 + c, columns 4 kk + g
     double Adm[KQ], Ad[KQ];
-    {
-      const int64_t n = n0 + c;
-      const bool ok = n < N;
-      const size_t o = (size_t)(ok ? n : N - 1) * QP + g;
 #pragma unroll
-      for (int kk = 0; kk < KQ; ++kk) {
-        const double dv = ok ? d2[o + 4 * kk] : 0.0, mv = Xmu[o + 4 * kk];
-        Ad[kk] = dv;
-        Adm[kk] = dv * mv;
-        r[c * TS + 4 * kk + g] = -0.5 * dv;                // -d2 / 2: the Gram product of the main kernel then yields the exponent itself
-      }
+    for (int kk = 0; kk < KQ; ++kk) {
+      Ad[kk] = dn[kk];
+      Adm[kk] = dn[kk] * mn[kk];
+      r[c * TS + 4 * kk + g] = -0.5 * dn[kk];                // -d2 / 2: the Gram product of the main kernel then yields the exponent itself
     }
+    if (tile + tstep < ntiles) fetch(tile + tstep);
     for (int i = lane; i < 16 * (TS - QP); i += 64) {      // zero padding of the d2 tile
       const int row = i / (TS - QP), col = QP + (i - row * (TS - QP));
       r[row * TS + col] = 0.0;
@@ -647,26 +652,52 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N,
   double dl_acc = 0.0, ws_acc = 0.0;
   const int rt = w & 1, ch = w >> 1;              // job A identity
 
+  // The next super-tile's rows are requested from global memory before the current one is worked on and go to LDS after it:
+  // thread t holds elements t, t + 256, ... of the [32][VW] image of V2.
+  constexpr int NV = 14, ND = 2 * CT;             // 32 VW / 256 = 2 MT <= 14;  32 * 16 CT / 256
+  double pvn[NV];
+  // (the element offsets are recomputed from an opaque copy of the thread index wherever they are used: hoisted out of the
+  // loop over the super-tiles they would occupy some sixty registers next to the accumulators)
+  auto fetch = [&](const int64_t st) {
+    const int64_t n0 = st * 32;
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = tt + 256 * k;
+      const int row = i / VW, col = i - row * VW;
+      const int64_t n = n0 + row;
+      pvn[k] = (k < 2 * MT && col < M2 && n < N) ? PV[(size_t)n * PW + col] : 0.0;
+    }
+  };
+  if ((int64_t)blockIdx.x < nst) fetch(blockIdx.x);
   for (int64_t st = blockIdx.x; st < nst; st += gridDim.x) {
     const int64_t n0 = st * 32;
     __syncthreads();                              // the previous epilogue is done with dS and wsS
-    for (int i = t; i < 32 * VW; i += 256) {
-      const int row = i / VW, col = i - row * VW;
-      const int64_t n = n0 + row;
-      vS[row * VS + col] = (col < M2 && n < N) ? 0.5 * PV[(size_t)n * PW + col] : 0.0;
-    }
-    for (int i = t; i < 32 * 16 * CT; i += 256) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (k < 2 * MT) {
+        const int i = tt + 256 * k;
+        const int row = i / VW, col = i - row * VW;
+        vS[row * VS + col] = 0.5 * pvn[k];
+      }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {                 // (d2 mu | d2): not prefetched (no gain measured), the registers go to the accumulators
+      const int i = tt + 256 * k;
       const int row = i / (16 * CT), col = i - row * (16 * CT);
-      const int half = col >= 16 * QT ? 1 : 0, qq = col - half * 16 * QT;
+      const int qq = col >= 16 * QT ? col - 16 * QT : col;
       const int64_t n = n0 + row;
       double v = 0.0;
       if (qq < QP && n < N) {
         const double dv = d2[(size_t)n * QP + qq];
-        v = half ? dv : dv * Xmu[(size_t)n * QP + qq];
+        v = col < 16 * QT ? dv * Xmu[(size_t)n * QP + qq] : dv;
       }
       dS[row * DS + col] = v;
     }
     __syncthreads();
+    if (st + gridDim.x < nst) fetch(st + gridDim.x);
     // ---- job B: K = the super-tile's 32 rows
     if (w < MT) {
 #pragma unroll 2
@@ -692,7 +723,7 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N,
     double wsum = 0.0;
     {
       const double* vr = vS + (16 * rt + c) * VS + g;
-#pragma unroll 4
+#pragma unroll 2
       for (int kk = 0; kk < K4; ++kk) {
         const double a = vr[4 * kk];
         wsum += a;
@@ -861,8 +892,8 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   const size_t lp = (2 * (size_t)16 * MT * (QP + 1) + 16 * MT) * sizeof(double);
   hipError_t e = hipFuncSetAttribute((const void*)psi2_pair_prep_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
   if (e != hipSuccess) return e;
-  int64_t prep_grid = (g.ntiles + 3) / 4;
-  if (prep_grid > 2 * (int64_t)g.NB) prep_grid = 2 * (int64_t)g.NB;
+  int64_t prep_grid = (g.ntiles + 3) / 4;                 // one round of workgroups: each pays for its LDS images of Z once
+  if (prep_grid > (int64_t)g.NB) prep_grid = g.NB;
   hipLaunchKernelGGL((psi2_pair_prep_kernel<QP>), dim3((unsigned)prep_grid), dim3(256), lp, s, N, g.ntiles, M, g.HS, g.RS, zt.Zc, zt.lam,
                      rt.Xmu, rt.d2, rt.g0, rec, PV, g.PW);
   PairArgs a{};
