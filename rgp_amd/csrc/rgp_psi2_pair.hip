@@ -30,12 +30,21 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#define PAIR_DEFAULT_MODE 0         // until the pair form beats the sweep kernels at the benchmark size
-#ifndef PAIR_NT
-#define PAIR_NT 4                 // pair tiles per wave (their C accumulators: 4 x QT x 4 doubles per lane)
+#define PAIR_DEFAULT_MODE 1         // the pair form where it pays (psi2_pair_selected)
+// Pair tiles per wave (their C accumulators: NT x QT x 4 doubles per lane), separately for the older waves 0-3 and the younger
+// waves 4-7 of a workgroup.  The hardware favours the older wave of a SIMD, which with equal work reaches the step's barrier
+// early and leaves the younger one to finish alone; giving the younger waves fewer tiles (4 + 2) was measured and does not pay
+// (10.7 M against 9.6 M cycles per launch at the benchmark size: their latency-bound phases starve behind the older wave's
+// matrix instructions whatever their length), so both get four.
+#ifndef PAIR_NT0
+#define PAIR_NT0 4
+#endif
+#ifndef PAIR_NT1
+#define PAIR_NT1 4
 #endif
 #define PAIR_WAVES 8
-#define PAIR_GROUP (PAIR_WAVES * PAIR_NT * 16)       // pairs per workgroup
+#define PAIR_TPG (4 * PAIR_NT0 + 4 * PAIR_NT1)       // pair tiles per workgroup
+#define PAIR_GROUP (16 * PAIR_TPG)                   // pairs per workgroup
 
 static __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -103,9 +112,9 @@ struct PairArgs {
 // group of matrix instructions are requested before the current group is issued -- with scheduling barriers between the groups.
 #define PAIR_HS 112               // row stride of the h' and V2 tiles (= 16 mod 32: the four row groups of a wave on disjoint banks); M <= 112
 #define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
-template <int QP>
-__global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
-  constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, NT = PAIR_NT, HS = PAIR_HS;
+template <int QP, int NT, bool role1>
+static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
+  constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, HS = PAIR_HS;
   constexpr int TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;       // T tile row stride: = 16 mod 32
   constexpr int RSP = (16 * (TS + HS) + 127) / 128 * 128;                    // record length: whole 1-KiB pieces
   constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * 16 * HS, O_TB = O_TT + 3 * 16 * TT,
@@ -125,7 +134,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool role1 = wave >= 4;
+  const int tb = role1 ? 4 * PAIR_NT0 + (wave - 4) * PAIR_NT1 : wave * PAIR_NT0;      // the wave's first tile within the pair group
   const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
   const int64_t t0 = a.ntiles * rr / a.RR, t1 = a.ntiles * (rr + 1) / a.RR;
   const int nsteps = (int)(t1 - t0);
@@ -160,11 +169,11 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
   // pairs 4 kk + g of the tile packed for the T product's right operand, c_p dLs
   int pvalid = 0, pkt[NT][2];
   int pa8[NT], pb8[NT];                                          // 8 a, 8 b of the lane's pair of tile k: every operand address derives from them
-  const int kpo = (O_KP + wave * (NT * 16) + c) * 8;
+  const int kpo = (O_KP + tb * 16 + c) * 8;
   constexpr int pso_d = (O_PS - O_KP) * 8, dlo_d = (O_DL - O_KP) * 8;     // pair sums and c_p dLs: the same slot of the next tables
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int tau = (gi * PAIR_WAVES + wave) * NT + k;
+    const int tau = gi * PAIR_TPG + tb + k;
     int pa, pb;
     const int p = 16 * tau + c;
     pair_ab(p, M, a.P, pa, pb);
@@ -246,6 +255,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 #ifdef PAIR_STAMPS
   long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long sq_[13], sprev_ = __builtin_readcyclecounter();
+  const unsigned long long clk0_ = sprev_, wall0_ = wall_clock64();       // core clock against the constant 100 MHz counter
 #endif
   int tt3 = 0;                                                   // s mod 3
   for (int s = 0; s < nsteps; ++s) {
@@ -506,13 +516,15 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 #ifdef PAIR_STAMPS
   if (a.dbg && lane == 0) {
     st_[15] = nsteps;
+    st_[13] = (long long)(__builtin_readcyclecounter() - clk0_);
+    st_[14] = (long long)(wall_clock64() - wall0_);
     for (int i = 0; i < 16; ++i) a.dbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = (double)st_[i];
   }
 #endif
   // ---- flush: C partial of this (row range, pair group), pair sums of psi2
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int tau = (gi * PAIR_WAVES + wave) * NT + k;
+    const int tau = gi * PAIR_TPG + tb + k;
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
       const int q = 16 * j + c;
@@ -528,6 +540,12 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
       a.p2_part[(size_t)rr * a.tri + hi * (hi + 1) / 2 + lo] = ps;
     }
   }
+}
+
+template <int QP>
+__global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
+  if (threadIdx.x < 256) psi2_pair_body<QP, PAIR_NT0, false>(a);
+  else psi2_pair_body<QP, PAIR_NT1, true>(a);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -848,7 +866,9 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   g.G = (g.P + PAIR_GROUP - 1) / PAIR_GROUP;
   g.Ppad = g.G * PAIR_GROUP;
   g.ntiles = (N + 15) / 16;
-  int64_t rr = (h->num_cu - (h->overlap && h->num_cu > 64 ? 1 : 0)) / g.G;
+  // One workgroup per CU, all resident at once: a workgroup that finds its CU taken by a kernel of the side streams would run
+  // as a second round and double the launch's duration, so a few CUs are left to those kernels.
+  int64_t rr = (h->num_cu - (h->overlap && h->num_cu > 64 ? 6 : 0)) / g.G;
   if (rr < 1) rr = 1;
   if (rr > g.ntiles) rr = g.ntiles;
   g.RR = (int)rr;
@@ -860,7 +880,9 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   return g.lds <= 160 * 1024;
 }
 
-// The pair form pays once a workgroup's 512 pairs are mostly real and every workgroup has a few steps of 16 rows to walk
+// The pair form pays once a workgroup's 512 pairs are mostly real and every workgroup has a hundred or more steps of 16 rows to
+// walk.  Measured against the sweep kernels at M = 100, Q = 40 / 40 / 20 (steps/s of the whole SVI step): 130432 rows 60.9 : 60.3,
+// 65216 rows 117.6 : 109.8, 32608 rows 207.7 : 206.6, 16304 rows 328 : 369.
 bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int mode = h->psi2_pair;
   if (mode < 0) {
@@ -871,7 +893,7 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   if (mode <= 0 || h->deterministic) return false;
   if (!psi2_pair_geom(h, N, M, QP, g)) return false;
   if (mode >= 2) return true;
-  return M >= 48 && N >= 2048;
+  return M >= 48 && N >= 49152;
 }
 
 size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N) {
@@ -914,6 +936,7 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
     static double hb[256 * 8 * 16];
     (void)hipMemcpy(hb, dbg_s, sizeof(hb), hipMemcpyDeviceToHost);
     const int nwg = g.G * g.RR;
+    fprintf(stderr, "pair QP=%d core clock during the step loop of workgroup 0: %.0f MHz\n", QP, 100.0 * hb[13] / (hb[14] > 0 ? hb[14] : 1));
     for (int role = 0; role < 2; ++role) {
       double acc[16] = {0};
       for (int wg = 0; wg < nwg; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int i = 0; i < 13; ++i)

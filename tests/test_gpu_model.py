@@ -245,13 +245,14 @@ def test_no_controls_and_wide_outputs():
         compare(o, g)
 
 
-def test_full_size_additivity_config4():
+@pytest.mark.parametrize('n', [8, 16])
+def test_full_size_additivity_config4(n):
     """BASELINE config-4 sizes (T=4096, D_y=16, M=100, wins=[0,20,20]): the size-independent identities the reference
     tests assert (testing/minibatch_tests.py:281-296) hold on the device: ELBO and global gradients are additive over a
-    split of the minibatch and invariant under a permutation of it."""
+    split of the minibatch and invariant under a permutation of it.  With 16 sequences the whole minibatch (65216 rows) runs
+    the pair form of the psi2 pass and each half (32608 rows) the sweep kernels, so the split also checks one against the other."""
     from rgp_amd.synthetic import CONFIG4 as cfg, generate_sequences
     from rgp_amd.model import DeepAutoreg
-    n = 8
     Us, Ys = generate_sequences(n, cfg['T'], cfg['D_y'], cfg['D_u'])
     m = DeepAutoreg(cfg['wins'], Ys, U=Us, U_win=cfg['U_win'], nDims=cfg['nDims'], X_variance=0.05, num_inducing=cfg['M'],
                     init='Y', inference_method='svi', mb_inf_tot_data_size=n, seed=3)

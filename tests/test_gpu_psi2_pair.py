@@ -1,6 +1,6 @@
 """The pair form of the fused psi2 pass (fp64 matrix pipe, rgp_amd/csrc/rgp_psi2_pair.hip) against the oracle.
 
-`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (the default picks it only for M >= 48 and >= 2048 rows), so the
+`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (the default picks it only for M >= 48 and >= 49152 rows), so the
 small shapes of the other tests can be run through it.  Tolerances as in test_gpu_kernels / test_gpu_model: gradients of the
 unit entry point 1e-10 of the largest entry, ELBO 1e-11, model gradients 1e-9."""
 import numpy as np
@@ -76,8 +76,8 @@ def test_many_steps_per_workgroup_and_minibatch():
     tile); then a minibatch of two of three ragged sequences (qU_ratio = 2/3)."""
     o, g = build_pair(wins=(0, 20, 20), nDims=(16, 1, 1), n_seq=1, T=7303, M=100, U_win=20, u_dim=1, y_dim=16, fast_psi=True,
                       chunk=512)
-    g.handle.set_psi2_pair(1)
-    compare(o, g)            # mode 1: M = 100 and 7283 rows select the pair form by themselves
+    g.handle.set_psi2_pair(2)
+    compare(o, g)
     o, g = build_pair(wins=(0, 6, 6), nDims=(3, 2, 2), n_seq=3, T=4001, M=12, U_win=6, ragged=True, n_total=3, fast_psi=True,
                       chunk=512)
     g.handle.set_psi2_pair(2)
