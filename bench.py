@@ -184,6 +184,7 @@ def main():
         # ---- roofline of the dominant kernel ----
         # algorithmic flops per (row, m, m') of the factorised form: Gram 2Q + y-update 2Q; the N*M*M exp evaluations are
         # listed separately (no fp64 transcendental unit: 14 VALU instructions each).
+        pair = False
         flops = 4.0 * psi2_nmmq                      # 4 Q flop per (n, m, m')
         if a.wide:                                   # executed count: three products over the M (M + 1) / 2 pairs, 2 N P Q flop each
             flops = 3.0 * psi2_nmmq * (cfg['M'] + 1.0) / cfg['M']
@@ -205,9 +206,21 @@ def main():
                      'algorithmic: the 5.27 GB of N x P weights written once, rewritten once and read three times')
         elif a.config == 4:
             metric = 'SVI steps/sec, 2-layer RGP M=100 T=4096 (ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
-            kernel = 'psi2_rowsP_kernel (fused psi2 forward+backward, packed teams, the two waves of a SIMD half a step apart, fp64 VALU, 3 launches per step: Q=40,40,20)'
-            traffic = measured_traffic_bytes('r2_psi2_rowsP_traffic_raw.json')
-            tnote = 'bytes per Q=40 launch from separate rocprofv3 --pmc passes (profiles/r2_psi2_rowsP_traffic_raw.json); algorithmic ~0.27e9'
+            rows = mb_loc * (T - cfg['U_win'])
+            pair = m.handle.psi2_pair_would_run(rows, cfg['M'], 2 * cfg['U_win'])
+            if pair:
+                kernel = ('fused psi2 pass in the pair form: psi2_pair_prep_kernel + psi2_pair_kernel (v_mfma_f64_16x16x4 over the '
+                          'M(M+1)/2 unordered pairs of inducing rows: Gram, C and T products, exponentials between them) + '
+                          'psi2_pair_rows_kernel + reduce + dz3; the time is that of the whole pass, 3 passes per step: Q=40,40,20')
+                traffic = measured_traffic_bytes('r3_psi2_pair_traffic_raw.json')
+                tnote = ('bytes per Q=40 pass (record, main and row kernels) from separate rocprofv3 --pmc passes '
+                         '(profiles/r3_psi2_pair_traffic_raw.json); algorithmic ~0.27e9; the pass moves more: 1.46e9 of fp64 atomic adds '
+                         'of the 10 pair groups into the N x 140 sums (resolved in L2/MALL, counted as writes), 0.17e9 of records, '
+                         '0.15e9 of sums read back')
+            else:
+                kernel = 'psi2_rowsP_kernel (fused psi2 forward+backward, packed teams, the two waves of a SIMD half a step apart, fp64 VALU, 3 launches per step: Q=40,40,20)'
+                traffic = measured_traffic_bytes('r2_psi2_rowsP_traffic_raw.json')
+                tnote = 'bytes per Q=40 launch from separate rocprofv3 --pmc passes (profiles/r2_psi2_rowsP_traffic_raw.json); algorithmic ~0.27e9'
         else:
             metric = 'SVI steps/sec, 3-layer RGP M=500 T=65536 D=64 (BASELINE config 5; ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
             kernel = ('big_psi2_bwd_kernel (psi2 backward sweep over inducing blocks, fp64 VALU, 4 launches per step: Q=40,40,40,20); the '
@@ -229,6 +242,9 @@ def main():
                                     'note': 'HIP events on the main stream between consecutive steps (rank 0); value uses the wall clock over all steps'},
             'roofline': {'bound': 'mfma', 'bound_note': 'fp64 MFMA (v_mfma_f64_16x16x4): with windows in the hundreds of columns the contraction '
                                                         'is three large matrix products' if a.wide else
+                                                        'fp64 MFMA (v_mfma_f64_16x16x4) for the three products of the pair form; the exponentials and '
+                                                        'operand products between them are fp64 VALU on the same pipe (costs add, '
+                                                        'profiles/r3_mfma_probes.txt)' if (a.config == 4 and pair) else
                                                         'fp64 VALU: the contract offers hbm|mfma; on MI355X the fp64 matrix pipe shares the vector '
                                                         'pipe\'s datapath and is slower (profiles/r1_f64_peak.txt), so the contraction runs as v_fma_f64',
                          'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -239,6 +255,10 @@ def main():
                          'note': ('flop = 3*N*M*(M+1)*Q per psi2 term as executed: three N x P x Q products over the P = M(M+1)/2 pairs of '
                                   'inducing rows (the dense factorised form counts 4*N*M*M*Q); each product alone runs at about 50 TFLOP/s '
                                   '(profiles/r2_wide_kernel_stats.csv)') if a.wide else
+                                 ('flop = 4*N*M*M*Q per pass, the count of the dense factorised form, kept so that the fraction compares with '
+                                  'earlier rounds; the pair form executes 3*N*M*(M+1)*Q (+ padding of Q to 16: 1.82e11 per Q=40 pass, '
+                                  'SQ_INSTS_VALU_MFMA_MOPS_F64 in profiles/r3_psi2_pair_counters.json) on the matrix pipe, which is busy 50 % '
+                                  'of the main kernel\'s time') if (a.config == 4 and pair) else
                                  ('flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
                                   'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q')},
         }

@@ -123,6 +123,9 @@ rgp_status rgp_set_deterministic(rgp_handle h, int on);
  * fits; -1 (default): the environment variable RGP_PSI2_PAIR if set, else 1.  rgp_set_deterministic(1) always selects the
  * fixed-order sweep kernel.  Results agree to rounding between the modes. */
 rgp_status rgp_set_psi2_pair(rgp_handle h, int mode);
+/* 1 if the fused psi2 pass of an SVI layer step with N data rows, M inducing points and Q window columns would run in the pair
+ * form under the handle's current mode, 0 if in the sweep kernels (a query for benchmarks and logs; no reference counterpart). */
+int        rgp_psi2_pair_would_run(rgp_handle h, int64_t N, int M, int Q);
 
 /* The library overlaps the M x M algebra and the row preparation with the psi passes on three streams of its own.  HIP maps
  * all streams of a process onto a few hardware queues in creation order (GPU_MAX_HW_QUEUES), and work on one hardware queue

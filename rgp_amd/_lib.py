@@ -66,6 +66,7 @@ SYMBOLS = {
     'rgp_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'rgp_set_deterministic': (C.c_int, [C.c_void_p, C.c_int]),
     'rgp_set_psi2_pair': (C.c_int, [C.c_void_p, C.c_int]),
+    'rgp_psi2_pair_would_run': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     'rgp_side_streams_independent': (C.c_int, [C.c_void_p]),
     'rgp_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     'rgp_vardtc_stats': (C.c_int, [C.c_void_p, C.POINTER(LayerIn), c_dp]),

@@ -78,6 +78,10 @@ class Handle(object):
         -1 the RGP_PSI2_PAIR environment variable or 1; include/rgp_hip.h rgp_set_psi2_pair."""
         self._check(self.lib.rgp_set_psi2_pair(self.h, int(mode)))
 
+    def psi2_pair_would_run(self, N, M, Q):
+        """True if the fused psi2 pass of an SVI layer step of this size runs in the pair form (include/rgp_hip.h)."""
+        return bool(self.lib.rgp_psi2_pair_would_run(self.h, int(N), int(M), int(Q)))
+
     def side_streams_independent(self):
         """How many of the library's three side streams run next to the main stream (include/rgp_hip.h)."""
         return int(self.lib.rgp_side_streams_independent(self.h))

@@ -242,6 +242,12 @@ extern "C" rgp_status rgp_set_psi2_pair(rgp_handle h, int mode) {
   return RGP_OK;
 }
 
+extern "C" int rgp_psi2_pair_would_run(rgp_handle h, int64_t N, int M, int Q) {
+  if (!h || N < 1 || M < 1 || Q < 1 || M > RGP_MAX_M || Q > RGP_MAX_QP) return 0;
+  PairGeom g;
+  return psi2_pair_selected(h, N, M, rgp_qp(Q), g) ? 1 : 0;
+}
+
 extern "C" rgp_status rgp_set_profiling(rgp_handle h, int on) {
   if (!h) return RGP_ERR_BAD_ARG;
   h->profiling = on != 0;
