@@ -116,6 +116,12 @@ template <int QP, int NT, bool role1>
 static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, HS = PAIR_HS;
   constexpr int TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;       // T tile row stride: = 16 mod 32
+  // Window columns of the C and T products: NF full tiles of 16 on v_mfma_f64_16x16x4 and NR groups of 4 on
+  // v_mfma_f64_4x4x4_4b (four 4x4x4 blocks, a quarter of the cycles): no matrix instruction is spent on the padding of Q to 16.
+  // In the small instruction lane (g, c) supplies the same left operands as in the large one (C: w[row 4 kk + g][pair c], T:
+  // w[row c][pair 4 kk + g]) and, as right operand, column c & 3 of the group at the row / pair g; its result lane holds
+  // C[pair 4 (c >> 2) + g][column c & 3] resp. T[row 4 (c >> 2) + g][column c & 3].
+  constexpr int NF = QP / 16, NR = (QP % 16) / 4, NF1 = NF > 0 ? NF : 1, NR1 = NR > 0 ? NR : 1, NE = NF + NR;
   constexpr int RSP = (16 * (TS + HS) + 127) / 128 * 128;                    // record length: whole 1-KiB pieces
   constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * 16 * HS, O_TB = O_TT + 3 * 16 * TT,
                 O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + PAIR_GROUP, O_DL = O_PS + PAIR_GROUP, O_Z = O_DL + PAIR_GROUP;
@@ -201,11 +207,16 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     g8 = (tl >> 1) & 0x18;
   };
   const int tbase = (O_TB + wave * (16 * 17)) * 8;                // this wave's transposition tile
-  d4 Cacc[NT][QT];
+  d4 Cacc[NT][NF1];
+  double CaccR[NT][NR1];
 #pragma unroll
   for (int k = 0; k < NT; ++k)
 #pragma unroll
-    for (int j = 0; j < QT; ++j) Cacc[k][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NF1; ++j) Cacc[k][j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int j = 0; j < NR1; ++j) CaccR[k][j] = 0.0;
   PAIR_BARRIER();
 
   // write-out slice of this thread: row t / 32 of the tile, columns t % 32 + 32 j.  Few loop invariants on purpose: two LDS
@@ -373,7 +384,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     }
     PAIR_SB();
     // right operand of the C product: requested now, it arrives under the V2 adds
-    double Bc[4][QT];
+    double Bc[4][NF1], BcR[4][NR1];
     {
       int c8b, g8b;
       lane8(c8b, g8b);
@@ -382,7 +393,15 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) Bc[r][j] = LDSD(boff + (4 * r * TS + 16 * j) * 8);
+        for (int j = 0; j < NF; ++j) Bc[r][j] = LDSD(boff + (4 * r * TS + 16 * j) * 8);
+      if (NR > 0) {
+        int boffR = g8b * TS + (c8b & 0x18) + inB;               // ... of the groups of 4 columns: d2[row 4 r + g][16 NF + 4 j + (c & 3)]
+        asm volatile("" : "+v"(boffR));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) BcR[r][j] = LDSD(boffR + (4 * r * TS + 16 * NF + 4 * j) * 8);
+      }
     }
     // V2 adds in one batch (fire and forget: they drain under the C product)
     int gHv;
@@ -404,35 +423,50 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     // requested ========
     auto c_quarter = [&](int r) {
 #pragma unroll
-      for (int j = 0; j < QT; ++j)
+      for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int k = 0; k < NT; ++k) Cacc[k][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[k][r], Bc[r][j], Cacc[k][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) CaccR[k][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(w[k][r], BcR[r][j], CaccR[k][j], 0, 0, 0);
     };
     // z values of k-step kk of pair tile k for the T product: rows of the pair 4 kk + g, columns 16 j + c
-    auto t_reads = [&](int zto, int k, int kk, double (&zra)[QT], double (&zrb)[QT]) {
+    // (columns 16 j + c for the full tiles j < NF, then 16 NF + 4 j' + (c & 3) for the groups of 4: entries NF + j')
+    auto t_reads = [&](int zto, int ztoR, int k, int kk, double (&zra)[NE], double (&zrb)[NE]) {
       const int pk = (pkt[k][kk >> 1] >> (16 * (kk & 1))) & 0xffff;
-      int oa = (pk & 0xff) * (ZS * 8) + zto, ob = (pk >> 8) * (ZS * 8) + zto;
-      asm volatile("" : "+v"(oa), "+v"(ob));
+      const int ra = (pk & 0xff) * (ZS * 8), rb = (pk >> 8) * (ZS * 8);
+      if (NF > 0) {
+        int oa = ra + zto, ob = rb + zto;
+        asm volatile("" : "+v"(oa), "+v"(ob));
 #pragma unroll
-      for (int j = 0; j < QT; ++j) { zra[j] = LDSD(oa + 128 * j); zrb[j] = LDSD(ob + 128 * j); }
+        for (int j = 0; j < NF; ++j) { zra[j] = LDSD(oa + 128 * j); zrb[j] = LDSD(ob + 128 * j); }
+      }
+      if (NR > 0) {
+        int oa = ra + ztoR, ob = rb + ztoR;
+        asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { zra[NF + j] = LDSD(oa + (16 * NF + 4 * j) * 8); zrb[NF + j] = LDSD(ob + (16 * NF + 4 * j) * 8); }
+      }
     };
-    int tbw, tbr, zto;
+    int tbw, tbr, zto, ztoR;
     {
       int c8t, g8t;
       lane8(c8t, g8t);
       tbw = tbase + g8t * 17 + c8t;                              // transposition tile: write [4 r + g][c]
       tbr = tbase + c8t * 17 + g8t;                              //                     read  [c][4 kk + g]
       zto = O_Z * 8 + c8t;                                       // Z image, T product's right operand: [pair's row][16 j + c]
+      ztoR = O_Z * 8 + (c8t & 0x18);                             //                     ... of the groups of 4: [pair's row][.. + (c & 3)]
     }
     c_quarter(0);
     PAIR_SB();
     PSTAMP(11);
-    double at[4], zra[QT], zrb[QT];
+    double at[4], zra[NE], zrb[NE];
 #pragma unroll
     for (int r = 0; r < 4; ++r) LDSD(tbw + r * (4 * 17 * 8)) = w[0][r];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) at[kk] = LDSD(tbr + kk * 32);
-    t_reads(zto, 0, 0, zra, zrb);
+    t_reads(zto, ztoR, 0, 0, zra, zrb);
     PAIR_SB();
     PSTAMP(12);
     c_quarter(1);
@@ -449,15 +483,18 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     // ======== T(s): T[16 rows x 16 q] += w (z z)^T, K = a tile's 16 pairs, one k-step (four pairs) at a time; the operands of the
     // next k-step (and, three k-steps into a tile, the next tile's transposed weights) are requested before the current one is
     // issued ========
-    d4 Tacc[QT];
+    d4 Tacc[NF1];
+    double TaccR[NR1];
 #pragma unroll
-    for (int j = 0; j < QT; ++j) Tacc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NF1; ++j) Tacc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < NR1; ++j) TaccR[j] = 0.0;
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
       double atn[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        double zna[QT], znb[QT];
+        double zna[NE], znb[NE];
         const bool last = (k == NT - 1 && kk == 3);
         if (kk == 2 && k + 1 < NT) {           // the tile's own transposed weights are in registers: the tile may be overwritten
 #pragma unroll
@@ -465,18 +502,20 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
           for (int k2 = 0; k2 < 4; ++k2) atn[k2] = LDSD(tbr + k2 * 32);
         }
-        if (kk < 3) t_reads(zto, k, kk + 1, zna, znb);
-        else if (!last) t_reads(zto, k + 1, 0, zna, znb);
-        double zz[QT];
+        if (kk < 3) t_reads(zto, ztoR, k, kk + 1, zna, znb);
+        else if (!last) t_reads(zto, ztoR, k + 1, 0, zna, znb);
+        double zz[NE];
 #pragma unroll
-        for (int j = 0; j < QT; ++j) zz[j] = zra[j] * zrb[j];
+        for (int j = 0; j < NE; ++j) zz[j] = zra[j] * zrb[j];
         PAIR_SB();
 #pragma unroll
-        for (int j = 0; j < QT; ++j) Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], zz[j], Tacc[j], 0, 0, 0);
+        for (int j = 0; j < NF; ++j) Tacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(at[kk], zz[j], Tacc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) TaccR[j] = __builtin_amdgcn_mfma_f64_4x4x4f64(at[kk], zz[NF + j], TaccR[j], 0, 0, 0);
         PAIR_SB();
         if (!last) {
 #pragma unroll
-          for (int j = 0; j < QT; ++j) { zra[j] = zna[j]; zrb[j] = znb[j]; }
+          for (int j = 0; j < NE; ++j) { zra[j] = zna[j]; zrb[j] = znb[j]; }
         }
       }
       if (k + 1 < NT) {
@@ -491,9 +530,15 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
       int tB = tBs + g8f * TT + c8f;                             // this lane's corner: [4 r + g][16 j + c]
       asm volatile("" : "+v"(tB));
 #pragma unroll
-      for (int j = 0; j < QT; ++j)
+      for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) atomicAdd(LDSP(tB + (4 * r * TT + 16 * j) * 8), Tacc[j][r]);
+      if (NR > 0) {                                              // the groups of 4 columns: this lane holds T[4 (c >> 2) + g][.. + (c & 3)]
+        int tR = tBs + ((c8f >> 5) * 4 * 8 + g8f) * TT + (c8f & 0x18);
+        asm volatile("" : "+v"(tR));
+#pragma unroll
+        for (int j = 0; j < NR; ++j) atomicAdd(LDSP(tR + (16 * NF + 4 * j) * 8), TaccR[j]);
+      }
     }
     PSTAMP(4);
     if (!role1) {
@@ -526,12 +571,14 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   for (int k = 0; k < NT; ++k) {
     const int tau = gi * PAIR_TPG + tb + k;
 #pragma unroll
-    for (int j = 0; j < QT; ++j) {
+    for (int j = 0; j < NF; ++j) {
       const int q = 16 * j + c;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (q < QP) a.Cpart[((size_t)rr * a.Ppad + 16 * tau + 4 * r + g) * QP + q] = Cacc[k][j][r];
+      for (int r = 0; r < 4; ++r) a.Cpart[((size_t)rr * a.Ppad + 16 * tau + 4 * r + g) * QP + q] = Cacc[k][j][r];
     }
+#pragma unroll
+    for (int j = 0; j < NR; ++j)                  // the groups of 4 columns: this lane holds C[pair 4 (c >> 2) + g][16 NF + 4 j + (c & 3)]
+      a.Cpart[((size_t)rr * a.Ppad + 16 * tau + 4 * (c >> 2) + g) * QP + 16 * NF + 4 * j + (c & 3)] = CaccR[k][j];
     const double ps = LDSD(kpo + pso_d + 128 * k);
     if (g == 0 && ((pvalid >> k) & 1)) {
       int pa, pb;
