@@ -43,6 +43,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define PAIR_NT1 4
 #endif
 #define PAIR_WAVES 8
+#ifndef PAIR_WO0
+#define PAIR_WO0 1                // 1: waves 0-3 alone write the finished V2 / T tiles out and request the records
+#endif
 #define PAIR_TPG (4 * PAIR_NT0 + 4 * PAIR_NT1)       // pair tiles per workgroup
 #define PAIR_GROUP (16 * PAIR_TPG)                   // pairs per workgroup
 
@@ -149,10 +152,10 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   // (inline asm: the compiler, unable to tell the DMA's LDS destination from the tiles the waves read meanwhile, would wait for
   // the transfer before the next LDS read; the waves wait for it themselves, with s_waitcnt vmcnt(0) in front of the barrier
   // that precedes the record's first use)
-  auto request_record = [&](int r) {
+  auto request_record = [&](int r, int nw) {           // by waves 0 .. nw - 1
     const double* src = a.rec + (size_t)(t0 + r) * RSP + lane * 2;
     const unsigned dst = (unsigned)(size_t)(inb + (r & 1) * RSP);
-    for (int ch = wave; ch * 128 < RSP; ch += PAIR_WAVES) {
+    for (int ch = wave; ch * 128 < RSP; ch += nw) {
       const double* gsrc = src + ch * 128;
       const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + ch * 1024);
       unsigned keep;
@@ -169,8 +172,8 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   }
   if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
   for (int i = t; i < 2 * 16 * HS + 3 * 16 * TT; i += 512) v2b[i] = 0.0;
-  if (nsteps > 0) request_record(0);
-  if (nsteps > 1) request_record(1);
+  if (nsteps > 0) request_record(0, PAIR_WAVES);
+  if (nsteps > 1) request_record(1, PAIR_WAVES);
   // per-lane constants: LDS byte offsets of this lane's operands (pair of tile k in the accumulator layout: column c), the
   // pairs 4 kk + g of the tile packed for the T product's right operand, c_p dLs
   int pvalid = 0, pkt[NT][2];
@@ -224,43 +227,53 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   double* pvp = a.PV + ((size_t)t0 * 16 + (t >> 5)) * a.PW + (t & 31);     // row of tile k, advanced after B_k
   int t3 = 2;                                                    // (k - 1) mod 3 at B_k
   // After barrier B_k: V2 tile k and T tile k - 1 are added to the global sums and cleared, record k + 2 is requested.
+  // The write-out is the older waves' job (PAIR_WO0): they reach the barrier early whatever they are given (the hardware favours
+  // the older wave of a SIMD), so the work every thread would share after the barrier is worth more taken off the younger waves,
+  // which are the ones the step waits for.  Thread t < 256 then handles rows t / 32 and t / 32 + 8 of the tiles.
   auto after_barrier = [&](int k) {
+    if (PAIR_WO0 && role1) return;
+    constexpr int NH = PAIR_WO0 ? 2 : 1;
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));                                 // the slice's offsets are recomputed here, not kept across the step
-    const int wrow = tq >> 5, wcol = tq & 31;
-    const int woff = wrow * HS + wcol, toff = wrow * TT + wcol;
+    const int wrow0 = tq >> 5, wcol = tq & 31;
     const int vslots = (a.M2 - wcol + 31) >> 5;                  // column slots of this thread in a V2 row (0..4)
     const int tslots = (QP - wcol + 31) >> 5;                    // ... in a T row (0..2)
     const int64_t left = a.N - (t0 + k) * 16;                    // valid rows of tile k
-    if (k < nsteps) {
-      double* const vrow = v2b + (k & 1) * (16 * HS) + woff;
-      const bool rok = wrow < left;
-      double v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (j < vslots) ? vrow[32 * j] : 0.0;
+    for (int h = 0; h < NH; ++h) {
+      const int wrow = wrow0 + 8 * h;
+      const int woff = wrow * HS + wcol, toff = wrow * TT + wcol;
+      double* const pv = pvp + 8 * h * (int64_t)a.PW;
+      if (k < nsteps) {
+        double* const vrow = v2b + (k & 1) * (16 * HS) + woff;
+        const bool rok = wrow < left;
+        double v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < vslots) {
-          vrow[32 * j] = 0.0;
-          if (rok) atomicAdd(&pvp[32 * j], v[j]);
-        }
-    }
-    if (k >= 1) {
-      double* const trow = ttb + t3 * (16 * TT) + toff;
-      double* const prow = pvp - 16 * (int64_t)a.PW + a.M2;
-      double v[2];
+        for (int j = 0; j < 4; ++j) v[j] = (j < vslots) ? vrow[32 * j] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) v[j] = (j < tslots) ? trow[32 * j] : 0.0;
+        for (int j = 0; j < 4; ++j)
+          if (j < vslots) {
+            vrow[32 * j] = 0.0;
+            if (rok) atomicAdd(&pv[32 * j], v[j]);
+          }
+      }
+      if (k >= 1) {
+        double* const trow = ttb + t3 * (16 * TT) + toff;
+        double* const prow = pv - 16 * (int64_t)a.PW + a.M2;
+        double v[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (j < tslots) {
-          trow[32 * j] = 0.0;
-          if (wrow < left + 16) atomicAdd(&prow[32 * j], v[j]);  // rows of tile k - 1 that exist
-        }
+        for (int j = 0; j < 2; ++j) v[j] = (j < tslots) ? trow[32 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < tslots) {
+            trow[32 * j] = 0.0;
+            if (wrow < left + 16) atomicAdd(&prow[32 * j], v[j]);  // rows of tile k - 1 that exist
+          }
+      }
     }
     pvp += 16 * (int64_t)a.PW;
     t3 = (t3 == 2) ? 0 : t3 + 1;
-    if (k + 2 < nsteps) request_record(k + 2);                   // last: no register reload may follow it before the next barrier
+    if (k + 2 < nsteps) request_record(k + 2, PAIR_WO0 ? 4 : PAIR_WAVES);     // last: no register reload may follow it before the next barrier
   };
 
 #ifdef PAIR_STAMPS
