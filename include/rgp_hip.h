@@ -119,7 +119,7 @@ rgp_status rgp_set_deterministic(rgp_handle h, int on);
 /* Which kernels run the fused psi2 pass of the SVI bound (kern.psi2 + its gradients, svi_vardtc.py:48-50, layers.py:98-132,
  * 1452-1458) for M <= 112, Q <= 64.  mode 0: the sweep kernels on the vector pipe (one thread per (data row, inducing row));
  * 1: the pair form on the fp64 matrix pipe (exponent, exponential and both back products once per UNORDERED pair of inducing
- * rows) where it pays (M >= 48 and >= 49152 data rows), the sweep kernels elsewhere; 2: the pair form wherever its LDS image
+ * rows) where it pays (M >= 48 and >= 12288 data rows), the sweep kernels elsewhere; 2: the pair form wherever its LDS image
  * fits; -1 (default): the environment variable RGP_PSI2_PAIR if set, else 1.  rgp_set_deterministic(1) always selects the
  * fixed-order sweep kernel.  Results agree to rounding between the modes. */
 rgp_status rgp_set_psi2_pair(rgp_handle h, int mode);

@@ -897,6 +897,7 @@ __global__ void __launch_bounds__(256) psi2_pair_dz3_kernel(const int M, const i
   const int q = i % QP, m = i / QP;           // consecutive threads walk q: coalesced reads of C
   if (m >= M) { slab[q * RGP_PSI2_TEAM + m] = 0.0; return; }
   double s = 0.0;
+#pragma unroll 8
   for (int mp = 0; mp < M; ++mp) {
     int d = mp - m, a = m;
     if (d < 0) d += M;
@@ -928,7 +929,17 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   g.ntiles = (N + 15) / 16;
   // One workgroup per CU, all resident at once: a workgroup that finds its CU taken by a kernel of the side streams would run
   // as a second round and double the launch's duration, so a few CUs are left to those kernels.
-  int64_t rr = (h->num_cu - (h->overlap && h->num_cu > 64 ? 6 : 0)) / g.G;
+  // A short pass (few steps per workgroup) leaves more: the side-stream kernels of the running step -- the previous layer's
+  // finalisation and update, the next layer's chain -- are then on the critical path and must not sit out the pass (measured at
+  // M = 100 on 256 CUs, steps/s with 250 / 240 / 230 / 220 / 210 workgroups: 4 sequences 354 / 374 / 367 / 395 / 386, 8 sequences
+  // 223 / 233 / 227 / 228 / 221, 16 sequences 128.9 / 126.3 with 250 / 240).
+  int spare = 0;
+  if (h->overlap && h->num_cu > 64) {
+    const int64_t steps = g.ntiles / ((h->num_cu - 6) / g.G > 0 ? (h->num_cu - 6) / g.G : 1);
+    spare = steps >= 128 ? 6 : (steps >= 64 ? 16 : 36);
+  }
+  if (const char* e = getenv("RGP_PSI2_PAIR_SPARE")) spare = atoi(e);
+  int64_t rr = (h->num_cu - spare) / g.G;
   if (rr < 1) rr = 1;
   if (rr > g.ntiles) rr = g.ntiles;
   g.RR = (int)rr;
@@ -940,9 +951,9 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   return g.lds <= 160 * 1024;
 }
 
-// The pair form pays once a workgroup's 512 pairs are mostly real and every workgroup has a hundred or more steps of 16 rows to
-// walk.  Measured against the sweep kernels at M = 100, Q = 40 / 40 / 20 (steps/s of the whole SVI step): 130432 rows 60.9 : 60.3,
-// 65216 rows 117.6 : 109.8, 32608 rows 207.7 : 206.6, 16304 rows 328 : 369.
+// The pair form pays once a workgroup's 512 pairs are mostly real and every workgroup has a few dozen steps of 16 rows to walk.
+// Measured against the sweep kernels at M = 100, Q = 40 / 40 / 20 (steps/s of the whole SVI step, pair : sweep):
+// 130432 rows 66.0 : 59.2, 65216 rows 128.9 : 109.7, 32608 rows 233 : 206, 16304 rows 395 : 370.  Smaller sizes were not measured.
 bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int mode = h->psi2_pair;
   if (mode < 0) {
@@ -953,7 +964,7 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   if (mode <= 0 || h->deterministic) return false;
   if (!psi2_pair_geom(h, N, M, QP, g)) return false;
   if (mode >= 2) return true;
-  return M >= 48 && N >= 49152;
+  return M >= 48 && N >= 12288;
 }
 
 size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N) {

@@ -245,12 +245,13 @@ def test_no_controls_and_wide_outputs():
         compare(o, g)
 
 
-@pytest.mark.parametrize('n', [8, 16])
+@pytest.mark.parametrize('n', [8, 4])
 def test_full_size_additivity_config4(n):
     """BASELINE config-4 sizes (T=4096, D_y=16, M=100, wins=[0,20,20]): the size-independent identities the reference
     tests assert (testing/minibatch_tests.py:281-296) hold on the device: ELBO and global gradients are additive over a
-    split of the minibatch and invariant under a permutation of it.  With 16 sequences the whole minibatch (65216 rows) runs
-    the pair form of the psi2 pass and each half (32608 rows) the sweep kernels, so the split also checks one against the other."""
+    split of the minibatch and invariant under a permutation of it.  With 4 sequences the whole minibatch (16304 rows) runs
+    the pair form of the psi2 pass and each half (8152 rows) the sweep kernels, so the split also checks one against the other;
+    with 8 everything runs the pair form (short and long passes)."""
     from rgp_amd.synthetic import CONFIG4 as cfg, generate_sequences
     from rgp_amd.model import DeepAutoreg
     Us, Ys = generate_sequences(n, cfg['T'], cfg['D_y'], cfg['D_u'])
