@@ -256,8 +256,8 @@ def main():
                                   'inducing rows (the dense factorised form counts 4*N*M*M*Q); each product alone runs at about 50 TFLOP/s '
                                   '(profiles/r2_wide_kernel_stats.csv)') if a.wide else
                                  ('flop = 4*N*M*M*Q per pass, the count of the dense factorised form, kept so that the fraction compares with '
-                                  'earlier rounds; the pair form executes 3*N*M*(M+1)*Q (+ padding of Q to 16: 1.82e11 per Q=40 pass, '
-                                  'SQ_INSTS_VALU_MFMA_MOPS_F64 in profiles/r3_psi2_pair_counters.json) on the matrix pipe, which is busy 50 % '
+                                  'earlier rounds; the pair form executes 3*N*M*(M+1)*Q (1.60e11 per Q=40 pass, '
+                                  'SQ_INSTS_VALU_MFMA_MOPS_F64 in profiles/r3_psi2_pair_counters.json) on the matrix pipe, which is busy 48 % '
                                   'of the main kernel\'s time') if (a.config == 4 and pair) else
                                  ('flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
                                   'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q')},
