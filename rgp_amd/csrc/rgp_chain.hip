@@ -2,8 +2,11 @@
 //
 // Restates SVI_VarDTC.inference + comp_KL_qU (autoreg/inference/svi_vardtc.py:70-215) and the q(U) gradient routing
 // of SparseGP_MPI._inference_vardtc (autoreg/layers.py:71-79,173-176) in terms of the explicit inverse factor
-// Linv = chol(Kuu + jitter I)^-1 (cond(L) = sqrt(cond(K)), so the explicit inverse costs no accuracy that matters at
-// the 1e-6 jitter the reference uses) -- every triangular solve of the reference becomes a small GEMM.
+// Linv = chol(Kuu + jitter I)^-1 (cond(L) = sqrt(cond(K))) -- every triangular solve of the reference becomes a small GEMM.
+// The gradient with respect to K_uu is kept in the reference's congruence form Linv^T (...) Linv: its entries are large and
+// cancel when dL/dZ is summed from them, and only an error of that form cancels with them.  (Through the explicit
+// K_uu^-1 = Linv^T Linv, as Kinv X Kinv, every entry is as accurate -- but dL/dZ loses a factor cond(K_uu): measured
+// 1e-7 against 1e-10 at cond 8e5, 2e-4 against 6e-9 at cond 6e7.)
 // The factorisations run in LDS (one padded M x M matrix, M <= 140); GEMMs run on L2-resident workspace matrices.
 #include "rgp_chain.h"
 #include "rgp_gemm.h"
@@ -388,10 +391,10 @@ static __device__ void wg_gemm(int m, int n, int k, double alpha, const double* 
 //                                                                    difference D I - B is formed before the congruence)
 //   -1/2 sum(B o A) + D/2 tr A  = sum(dL_dpsi2 o psi2)              (:113-123, A = beta Linv psi2 Linv^T never formed)
 //   sum(gmu o Ybt)              = sum(Cpsi1 o psi1Y^T)
-//   mA = -Linv^T A Linv         = -beta Kinv psi2 Kinv              (:145)
-//   1/2 (t1 + t1^T) - D/2 Linv^T A Linv = -(R + R^T) - D/2 mA,  R = dL_dpsi2 psi2 Kinv      (:129-133)
-//   Linv^T (gmu Ybt^T) Linv     = Kinv_mu Vt^T,  Vt = beta Kinv psi1Y^T
-//   dKL_dK = D/2 Kinv - 1/2 Kinv V Kinv = dL_dpsi2 / beta           (:213)
+//   A = beta Linv psi2 Linv^T;  mA = -Linv^T A Linv                 (:107,145)
+//   dL_dKmm - ratio dKL_dK = Linv^T [ 1/2 (B A + A B) - D/2 A - 1/2 (t2 + t2^T) - ratio (D/2 I - B/2) ] Linv,
+//                            t2 = gmu Ybar, Ybar^T = beta Linv psi1Y^T          (:129-133, 213: ONE congruence)
+//   dL_dqU_mean = mA mu + Linv^T Ybar^T                             (:146)
 //   D/2 ||E||_F^2 + 1/2 ||gmu||_F^2 = 1/2 tr B                      (:209)
 //   woodbury_inv = Linv^T (I - E E^T) Linv = (2 / (beta D)) dL_dpsi2 + Kinv_mu Kinv_mu^T / D     (:154)
 // ==================================================================================================================
@@ -477,13 +480,12 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   const double Dd = (double)D, Nd = (double)c.N;
   const double beta = 1.0 / c.noise[0];
   const double ratio = c.qU_ratio;
-  // X = psi2 Kinv ;  mA = -beta Kinv X ;  R = dL_dpsi2 X
-  wg_gemm<false, false>(M, M, M, 1.0, c.psi2, M, c.Kinv, M, 0.0, c.T1, M, lds);
-  wg_gemm<false, false>(M, M, M, -beta, c.Kinv, M, c.T1, M, 0.0, c.mA, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, c.dLdpsi2, M, c.T1, M, 0.0, c.T2, M, lds);
-  // Vt (M x D) = beta Kinv psi1Y^T ;  Wm = Kinv_mu Vt^T
-  wg_gemm<false, true>(M, D, M, beta, c.Kinv, M, c.psi1Y, M, 0.0, c.Ybt, D, lds);
-  wg_gemm<false, true>(M, M, D, 1.0, c.Kinv_mu, D, c.Ybt, D, 0.0, c.T3, M, lds);
+  // A = beta Linv psi2 Linv^T -> T2 ;  B A -> T3 ;  Ybar^T = beta Linv psi1Y^T -> Ybt (M x D) ;  t2 = gmu Ybar -> dKmm (scratch)
+  wg_gemm<false, true>(M, M, M, 1.0, c.psi2, M, c.Linv, M, 0.0, c.T1, M, lds);
+  wg_gemm<false, false>(M, M, M, beta, c.Linv, M, c.T1, M, 0.0, c.T2, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.B, M, c.T2, M, 0.0, c.T3, M, lds);
+  wg_gemm<false, true>(M, D, M, beta, c.Linv, M, c.psi1Y, M, 0.0, c.Ybt, D, lds);
+  wg_gemm<false, true>(M, M, D, 1.0, c.gmu, D, c.Ybt, D, 0.0, c.dKmm, M, lds);
   double sP = 0.0, gY = 0.0;
   for (int i = t; i < M * M; i += blockDim.x) sP += c.dLdpsi2[i] * c.psi2[i];
   for (int i = t; i < M * D; i += blockDim.x) gY += c.Cpsi1[i] * c.psi1Y[(size_t)(i % D) * M + i / D];
@@ -492,15 +494,22 @@ __global__ void __launch_bounds__(CH_THREADS) svi_chain_post_kernel(SviChain c) 
   const double logL = -0.5 * Nd * Dd * LOG_2PI + 0.5 * Dd * Nd * log(beta) + data_fit;            // :121-123
   const double dthetaL = -0.5 * Dd * Nd * beta - data_fit * beta;                                   // :139
   const double KL = -0.5 * Dd * M - Dd * c.scal[1] + Dd * c.scal[0] + 0.5 * c.scal[2];               // :209
-  // dL_dKmm (:129-133) minus ratio dKL_dK (:213);  dL_dqU_mean = mA mu + Vt (:146);  dL_dqU_var = D/2 mA (:147)
-  const double rb = ratio / beta;
+  // dL_dKmm (:129-133) minus ratio dKL_dK (:213) as one congruence;  mA (:145);  dL_dqU_mean = mA mu + Linv^T Ybar^T (:146);
+  // dL_dqU_var = D/2 mA (:147)
   for (int i = t; i < M * M; i += blockDim.x) {
     const int r = i / M, cc = i % M, it = cc * M + r;
-    c.dKmm[i] = -(c.T2[i] + c.T2[it]) - 0.25 * Dd * (c.mA[i] + c.mA[it]) - 0.5 * (c.T3[i] + c.T3[it]) - rb * c.dLdpsi2[i];
-    // Gv = dL_dqU_var - ratio dKL_dvar = D/2 mA - ratio D/2 (Kinv - Sinv)
-    c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);
+    c.T1[i] = 0.5 * (c.T3[i] + c.T3[it]) - 0.5 * Dd * c.T2[i] - 0.5 * (c.dKmm[i] + c.dKmm[it])
+              - ratio * ((r == cc ? 0.5 * Dd : 0.0) - 0.5 * c.B[i]);
   }
-  for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] = c.Ybt[i] - ratio * c.Kinv_mu[i];
+  __syncthreads();
+  wg_gemm<false, false>(M, M, M, 1.0, c.T1, M, c.Linv, M, 0.0, c.T3, M, lds);
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T3, M, 0.0, c.dKmm, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.T2, M, c.Linv, M, 0.0, c.T3, M, lds);
+  wg_gemm<true, false>(M, M, M, -1.0, c.Linv, M, c.T3, M, 0.0, c.mA, M, lds);
+  wg_gemm<true, false>(M, D, M, 1.0, c.Linv, M, c.Ybt, D, 0.0, c.gqm, D, lds);
+  for (int i = t; i < M * M; i += blockDim.x)
+    c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);      // dL_dqU_var - ratio dKL_dvar
+  for (int i = t; i < M * D; i += blockDim.x) c.gqm[i] -= ratio * c.Kinv_mu[i];
   __syncthreads();
   wg_gemm<false, false>(M, D, M, 1.0, c.mA, M, c.qU_m, D, 1.0, c.gqm, D, lds);
   // q(U) parameter gradients (layers.py:173-176)
@@ -623,10 +632,11 @@ __global__ void big_scal_kernel(SviChain c) {
 //       2  T1 = D I - B
 //       3  dLs_sym = 1/2 (dLdpsi2 + dLdpsi2^T)
 //       4  Wi = 2/(beta D) dLdpsi2
-//       5  dKmm, Gv                                  (svi_vardtc.py:129-133,147,213 as in svi_chain_post_kernel)
-//       6  gqm = Ybt - ratio Kinv_mu                 (M x D)
+//       5  Gv                                        (svi_vardtc.py:147,213 as in svi_chain_post_kernel)
+//       6  gqm -= ratio Kinv_mu                      (M x D)
 //       7  T1 = Gv + Gv^T
 //       8  copy S to LsInv's storage (factored in place there)
+//       9  T1 = inner matrix of the congruence that yields dL_dKmm - ratio dKL_dK   (:129-133,213; t2 in dKmm)
 __global__ void __launch_bounds__(256) big_elem_kernel(SviChain c, int what) {
   const int M = c.M, D = c.D;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -640,14 +650,14 @@ __global__ void __launch_bounds__(256) big_elem_kernel(SviChain c, int what) {
     case 2: if (i < mm) c.T1[i] = (r == cc ? Dd : 0.0) - c.B[i]; break;
     case 3: if (i < mm && c.dLs_sym) c.dLs_sym[i] = 0.5 * (c.dLdpsi2[i] + c.dLdpsi2[it]); break;
     case 4: if (i < mm) c.Wi[i] = c.scal[6] * c.dLdpsi2[i]; break;
-    case 5: if (i < mm) {
-      const double ratio = c.qU_ratio, rb = ratio / c.scal[3];
-      c.dKmm[i] = -(c.T2[i] + c.T2[it]) - 0.25 * Dd * (c.mA[i] + c.mA[it]) - 0.5 * (c.T3[i] + c.T3[it]) - rb * c.dLdpsi2[i];
-      c.Gv[i] = 0.5 * Dd * c.mA[i] - ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]);
-    } break;
-    case 6: if (i < md) c.gqm[i] = c.Ybt[i] - c.qU_ratio * c.Kinv_mu[i]; break;
+    case 5: if (i < mm) c.Gv[i] = 0.5 * Dd * c.mA[i] - c.qU_ratio * 0.5 * Dd * (c.Kinv[i] - c.Sinv[i]); break;
+    case 6: if (i < md) c.gqm[i] -= c.qU_ratio * c.Kinv_mu[i]; break;
     case 7: if (i < mm) c.T1[i] = c.Gv[i] + c.Gv[it]; break;
     case 8: if (i < mm) c.LsInv[i] = c.S[i]; break;
+    case 9: if (i < mm)
+      c.T1[i] = 0.5 * (c.T3[i] + c.T3[it]) - 0.5 * Dd * c.T2[i] - 0.5 * (c.dKmm[i] + c.dKmm[it])
+                - c.qU_ratio * ((r == cc ? 0.5 * Dd : 0.0) - 0.5 * c.B[i]);
+      break;
     default: break;
   }
 }
@@ -725,12 +735,19 @@ static rgp_status svi_chain_pre_big(rgp_handle h, const SviChain& c, hipStream_t
 
 static rgp_status svi_chain_post_big(rgp_handle h, const SviChain& c, hipStream_t s) {
   const int M = c.M, D = c.D;
-  // X = psi2 Kinv ; mA = -beta Kinv X ; R = dL_dpsi2 X ; Vt = beta Kinv psi1Y^T ; Wm = Kinv_mu Vt^T
-  gemm(s, M, M, M, 1.0, c.psi2, M, false, c.Kinv, M, false, 0.0, c.T1, M);
-  gemm(s, M, M, M, 1.0, c.Kinv, M, false, c.T1, M, false, 0.0, c.mA, M, c.scal + 5);
-  gemm(s, M, M, M, 1.0, c.dLdpsi2, M, false, c.T1, M, false, 0.0, c.T2, M);
-  gemm(s, M, D, M, 1.0, c.Kinv, M, false, c.psi1Y, M, true, 0.0, c.Ybt, D, c.scal + 3);
-  gemm(s, M, M, D, 1.0, c.Kinv_mu, D, false, c.Ybt, D, true, 0.0, c.T3, M);
+  // A = beta Linv psi2 Linv^T -> T2 ; B A -> T3 ; Ybar^T = beta Linv psi1Y^T -> Ybt ; t2 = gmu Ybar -> dKmm (scratch) ;
+  // inner matrix -> T1 ; dKmm = Linv^T T1 Linv ; mA = -Linv^T A Linv ; gqm = Linv^T Ybar^T - ratio Kinv_mu (+ mA mu below)
+  gemm(s, M, M, M, 1.0, c.psi2, M, false, c.Linv, M, true, 0.0, c.T1, M);
+  gemm(s, M, M, M, 1.0, c.Linv, M, false, c.T1, M, false, 0.0, c.T2, M, c.scal + 3);
+  gemm(s, M, M, M, 1.0, c.B, M, false, c.T2, M, false, 0.0, c.T3, M);
+  gemm(s, M, D, M, 1.0, c.Linv, M, false, c.psi1Y, M, true, 0.0, c.Ybt, D, c.scal + 3);
+  gemm(s, M, M, D, 1.0, c.gmu, D, false, c.Ybt, D, true, 0.0, c.dKmm, M);
+  big_elem(s, c, 9, false);
+  gemm(s, M, M, M, 1.0, c.T1, M, false, c.Linv, M, false, 0.0, c.T3, M);
+  gemm(s, M, M, M, 1.0, c.Linv, M, true, c.T3, M, false, 0.0, c.dKmm, M);
+  gemm(s, M, M, M, 1.0, c.T2, M, false, c.Linv, M, false, 0.0, c.T3, M);
+  gemm(s, M, M, M, -1.0, c.Linv, M, true, c.T3, M, false, 0.0, c.mA, M);
+  gemm(s, M, D, M, 1.0, c.Linv, M, true, c.Ybt, D, false, 0.0, c.gqm, D);
   big_elem(s, c, 5, false);
   big_elem(s, c, 6, true);
   gemm(s, M, D, M, 1.0, c.mA, M, false, c.qU_m, D, false, 1.0, c.gqm, D);
@@ -823,7 +840,7 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
   // D I - LL^-T (C + D I) LL^-1 and I - LL^-T LL^-1, which are differences themselves):
   //   tr C = ||b||_F^2 (+ beta^2 sum(G2 o PsiR));   Li^T C Li = v^T v (+ beta^2 G2 PsiR G2)
   //   R = 1/2 [D Kinv - D G2 - Li^T C Li]                                                 (:140-141)
-  //   Linv^T A Linv = beta Kinv psi2 Kinv                                                 (:155)
+  //   Linv^T A Linv stays a congruence (two products with Linv)                           (:155)
   //   woodbury_inv = Kinv - G2                                                            (:161)
   double* Kinv = c.C;
   wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.Linv, M, 0.0, Kinv, M, lds);
@@ -840,12 +857,12 @@ __global__ void __launch_bounds__(CH_THREADS) vardtc_chain_kernel(VarDtcChain c)
     wg_gemm<false, false>(M, M, M, 1.0, c.G2, M, c.PsiR, M, 0.0, c.T2, M, lds);
     wg_gemm<false, false>(M, M, M, -beta * beta, c.T2, M, c.G2, M, 1.0, c.T1, M, lds);
   }
-  wg_gemm<false, false>(M, M, M, 1.0, c.psi2, M, Kinv, M, 0.0, c.T2, M, lds);
-  wg_gemm<false, false>(M, M, M, 1.0, Kinv, M, c.T2, M, 0.0, c.T3, M, lds);
+  wg_gemm<false, false>(M, M, M, 1.0, c.A, M, c.Linv, M, 0.0, c.T2, M, lds);             // Linv^T A Linv as the congruence it is:
+  wg_gemm<true, false>(M, M, M, 1.0, c.Linv, M, c.T2, M, 0.0, c.T3, M, lds);              // see the header on dL/dZ
   for (int i = t; i < M * M; i += blockDim.x) {
     const double R = 0.5 * c.T1[i];
     c.R[i] = R;
-    c.dKmm[i] = R - 0.5 * Dd * beta * c.T3[i];
+    c.dKmm[i] = R - 0.5 * Dd * c.T3[i];
     c.dLdpsi2[i] = beta * R;
     sR += R * beta * c.psi2[i];
     if (c.winv) c.winv[i] = Kinv[i] - c.G2[i];
@@ -880,7 +897,7 @@ __global__ void __launch_bounds__(256) vd_elem_kernel(VarDtcChain c, int what) {
     const double beta = c.beta[0];
     const double R = 0.5 * c.T1[i];
     c.R[i] = R;
-    c.dKmm[i] = R - 0.5 * Dd * beta * c.T3[i];
+    c.dKmm[i] = R - 0.5 * Dd * c.T3[i];
     c.dLdpsi2[i] = beta * R;
     if (c.winv) c.winv[i] = c.C[i] - c.G2[i];
   }
@@ -930,8 +947,8 @@ static rgp_status vardtc_chain_big(rgp_handle h, const VarDtcChain& c, hipStream
     gemm(s, M, M, M, 1.0, c.G2, M, false, c.PsiR, M, false, 0.0, c.T2, M);
     gemm(s, M, M, M, -1.0, c.T2, M, false, c.G2, M, false, 1.0, c.T1, M, c.scal + 1);
   }
-  gemm(s, M, M, M, 1.0, c.psi2, M, false, c.C, M, false, 0.0, c.T2, M);
-  gemm(s, M, M, M, 1.0, c.C, M, false, c.T2, M, false, 0.0, c.T3, M);
+  gemm(s, M, M, M, 1.0, c.A, M, false, c.Linv, M, false, 0.0, c.T2, M);            // Linv^T A Linv as a congruence
+  gemm(s, M, M, M, 1.0, c.Linv, M, true, c.T2, M, false, 0.0, c.T3, M);
   hipLaunchKernelGGL(vd_elem_kernel, dim3(eb), dim3(256), 0, s, c, 2);
   hipLaunchKernelGGL(vd_final_kernel, dim3(1), dim3(CH_THREADS), 0, s, c);
   hipError_t e = hipGetLastError();

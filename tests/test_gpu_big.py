@@ -207,19 +207,19 @@ def test_big_freerun_matches_oracle(M, inference):
     in blocks of 512 (M > 512)."""
     from test_gpu_model import compare
     o, g = _pair(n_seq=2, T=16, M=M, inference=inference)
-    # Hundreds of inducing points in 6 to 15 input dimensions: K_uu + 1e-6 I is ill conditioned.  The device chain forms
-    # dL/dK_uu from explicit inverse factors, the oracle from triangular solves.  Both reach every chain output to about
-    # eps * cond (tools/chain_accuracy.py compares them with an extended-precision evaluation), but dL/dZ sums hundreds of large
-    # entries of dL/dK_uu that cancel, and only the solves' error has the structure that cancels with them: the device's dL/dZ is
-    # good to about 1e-2 * eps * cond^2 (measured: 8e-12 at cond 5e3, 3e-8 at 1e5, 2e-6 at 3e6), the oracle's to about eps * cond.
-    # The gate follows that law, with the condition number computed here, and is never tighter than the 1e-8 of the file header.
+    # Hundreds of inducing points in 6 to 15 input dimensions: K_uu + 1e-6 I is ill conditioned (cond ~ 1e5 here), and the two
+    # sides factor it in different orders (blocked Cholesky and explicit inverse factor here, one triangular solve per use in the
+    # oracle).  Both keep dL/dK_uu in the congruence form Linv^T (...) Linv, whose error cancels in the sum that yields dL/dZ
+    # (tools/chain_accuracy.py compares both with an extended-precision evaluation: each is good to a small multiple of
+    # eps * cond).  The gate is 50 eps cond, with the condition number computed here, and never tighter than the 1e-8 of the
+    # file header.
     from test_gpu_model import worst_cond, rounding_sensitivity
     cond = worst_cond(o)
     sens = rounding_sensitivity(o)
-    rtol = max(1e-8, 0.05 * np.finfo(float).eps * cond ** 2)
+    rtol = max(1e-8, 50.0 * np.finfo(float).eps * cond)
     print('M = %d %s: cond(K_uu + 1e-6 I) = %.3g, gradient gate %.2g; one ulp of the inputs moves the oracle\'s gradients by up to %.2g'
           % (M, inference, cond, rtol, max(sens.values())))
-    assert cond < 1e6                                   # beyond that the gate would say nothing
+    assert cond < 1e7                                   # beyond that the gate would say little
     compare(o, g, rtol=rtol)
     U = np.random.default_rng(8).standard_normal((12, 2))
     want, got = o.freerun(U), g.freerun(U)

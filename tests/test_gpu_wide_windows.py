@@ -41,12 +41,12 @@ def test_wide_window_freerun_matches_oracle(cfg):
     """Moment-matching free-run through layers with wide windows (layers.py:1537-1571): the generic-Q kernel vs the oracle."""
     import numpy as np
     o, g = build_pair(fast_psi=True, chunk=8, **cfg)
-    # many inducing points in few input dimensions: dL/dZ of the device chain is good to about 1e-2 * eps * cond(K_uu)^2
-    # (test_gpu_big.test_big_freerun_matches_oracle explains and measures it); the gate is that, and at least 1e-9 / 1e-8
+    # many inducing points in few input dimensions: the gate is 1e-9 / 1e-8, or 50 eps cond(K_uu + 1e-6 I) where that is more
+    # (test_gpu_big.test_big_freerun_matches_oracle)
     cond = worst_cond(o)
-    rtol = max(1e-9 if cfg['M'] <= 128 else 1e-8, 0.05 * np.finfo(float).eps * cond ** 2)
+    rtol = max(1e-9 if cfg['M'] <= 128 else 1e-8, 50.0 * np.finfo(float).eps * cond)
     print('M = %d: cond(K_uu + 1e-6 I) = %.3g, gradient gate %.2g' % (cfg['M'], cond, rtol))
-    assert cond < 1e6
+    assert cond < 1e7
     compare(o, g, rtol=rtol)                                    # also fills the posteriors
     U = np.random.default_rng(9).standard_normal((cfg['U_win'] + 25, cfg['u_dim']))
     want, got = o.freerun(U), g.freerun(U)
