@@ -16,7 +16,8 @@
 // free on the matrix pipe), so the exponent, the exponential and the two back products are evaluated on M (M + 1) / 2 instead of
 // M^2 entries per data row: 6 N P Q = 3 N M (M + 1) Q multiply-add flop against 4 N M^2 Q of the sweep kernels.
 //
-// Ownership.  A workgroup of eight waves owns 512 pairs (4 tiles of 16 pairs per wave) and a range of data rows, walked in steps
+// Ownership.  A workgroup of eight waves owns 512 pairs (4 tiles of 16 pairs per wave; 640 = 5 tiles per wave for windows of up
+// to 20 columns, whose C accumulators are smaller) and a range of data rows, walked in steps
 // of 16 rows.  Per step a wave runs, for each of its pair tiles, v_mfma_f64_16x16x4 products
 //   Gram  [16 rows x 16 pairs], K = Q     A = d2 row tile (LDS), B = z[a,q] z[b,q] formed on the fly from the Z image in LDS
 //   C     [16 pairs x 16 q] x QT, K = 16 rows   A = the weights as they stand in the accumulator layout, B = d2 row tile
@@ -31,23 +32,21 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define PAIR_DEFAULT_MODE 1         // the pair form where it pays (psi2_pair_selected)
-// Pair tiles per wave (their C accumulators: NT x QT x 4 doubles per lane), separately for the older waves 0-3 and the younger
-// waves 4-7 of a workgroup.  The hardware favours the older wave of a SIMD, which with equal work reaches the step's barrier
-// early and leaves the younger one to finish alone; giving the younger waves fewer tiles (4 + 2) was measured and does not pay
-// (10.7 M against 9.6 M cycles per launch at the benchmark size: their latency-bound phases starve behind the older wave's
-// matrix instructions whatever their length), so both get four.
-#ifndef PAIR_NT0
-#define PAIR_NT0 4
+// Pair tiles per wave (their C accumulators: NT x (8 NF + 2 NR) registers per lane): four, five where the window is narrow
+// enough for the registers (the step's fixed work -- barrier, record, write-out -- is then shared by more pairs: 67.7 against
+// 65.9 steps/s at the benchmark size from the Q = 20 pass alone; six spill).
+// (The hardware favours the older wave of a SIMD, which with equal work reaches the step's barrier early and leaves the younger
+// one to finish alone; giving the younger waves fewer tiles (4 + 2) was measured and does not pay: 10.7 M against 9.6 M cycles per
+// launch at the benchmark size.)
+#ifndef PAIR_NT_NARROW
+#define PAIR_NT_NARROW 5
 #endif
-#ifndef PAIR_NT1
-#define PAIR_NT1 4
-#endif
+static constexpr int pair_nt(int QP) { return QP <= 20 ? PAIR_NT_NARROW : 4; }
 #define PAIR_WAVES 8
 #ifndef PAIR_WO0
 #define PAIR_WO0 1                // 1: waves 0-3 alone write the finished V2 / T tiles out and request the records
 #endif
-#define PAIR_TPG (4 * PAIR_NT0 + 4 * PAIR_NT1)       // pair tiles per workgroup
-#define PAIR_GROUP (16 * PAIR_TPG)                   // pairs per workgroup
+#define PAIR_GROUP_MAX (128 * 6)                     // pairs per workgroup at most (8 waves x NT tiles x 16)
 
 static __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -127,7 +126,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   constexpr int NF = QP / 16, NR = (QP % 16) / 4, NF1 = NF > 0 ? NF : 1, NR1 = NR > 0 ? NR : 1, NE = NF + NR;
   constexpr int RSP = (16 * (TS + HS) + 127) / 128 * 128;                    // record length: whole 1-KiB pieces
   constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * 16 * HS, O_TB = O_TT + 3 * 16 * TT,
-                O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + PAIR_GROUP, O_DL = O_PS + PAIR_GROUP, O_Z = O_DL + PAIR_GROUP;
+                O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + 128 * NT, O_DL = O_PS + 128 * NT, O_Z = O_DL + 128 * NT;
   extern __shared__ double lds[];
   // LDS operands are addressed by their byte offset in the workgroup's LDS image: the kernel has no static LDS, so the dynamic
   // image starts at offset 0 and an offset is the whole address (no base register, no add in front of every access)
@@ -143,7 +142,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tb = role1 ? 4 * PAIR_NT0 + (wave - 4) * PAIR_NT1 : wave * PAIR_NT0;      // the wave's first tile within the pair group
+  const int tb = wave * NT;                                      // the wave's first tile within the pair group
   const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
   const int64_t t0 = a.ntiles * rr / a.RR, t1 = a.ntiles * (rr + 1) / a.RR;
   const int nsteps = (int)(t1 - t0);
@@ -182,7 +181,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   constexpr int pso_d = (O_PS - O_KP) * 8, dlo_d = (O_DL - O_KP) * 8;     // pair sums and c_p dLs: the same slot of the next tables
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int tau = gi * PAIR_TPG + tb + k;
+    const int tau = gi * (8 * NT) + tb + k;
     int pa, pb;
     const int p = 16 * tau + c;
     pair_ab(p, M, a.P, pa, pb);
@@ -535,7 +534,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) at[k2] = atn[k2];
       }
-      PSTAMP(7 + k);
+      if (k < 4) PSTAMP(7 + k);
     }
     {
       int c8f, g8f;
@@ -582,7 +581,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   // ---- flush: C partial of this (row range, pair group), pair sums of psi2
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const int tau = gi * PAIR_TPG + tb + k;
+    const int tau = gi * (8 * NT) + tb + k;
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
       const int q = 16 * j + c;
@@ -604,8 +603,8 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 
 template <int QP>
 __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
-  if (threadIdx.x < 256) psi2_pair_body<QP, PAIR_NT0, false>(a);
-  else psi2_pair_body<QP, PAIR_NT1, true>(a);
+  if (threadIdx.x < 256) psi2_pair_body<QP, pair_nt(QP), false>(a);
+  else psi2_pair_body<QP, pair_nt(QP), true>(a);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -924,8 +923,9 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   g.M2 = (M + 1) & ~1;
   g.PW = g.M2 + QP;
   g.P = M * (M + 1) / 2;
-  g.G = (g.P + PAIR_GROUP - 1) / PAIR_GROUP;
-  g.Ppad = g.G * PAIR_GROUP;
+  const int group = 128 * pair_nt(QP);                                  // pairs per workgroup
+  g.G = (g.P + group - 1) / group;
+  g.Ppad = g.G * group;
   g.ntiles = (N + 15) / 16;
   // One workgroup per CU, all resident at once: a workgroup that finds its CU taken by a kernel of the side streams would run
   // as a second round and double the launch's duration, so a few CUs are left to those kernels.
@@ -947,11 +947,11 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   if (nb > g.ntiles) nb = g.ntiles;
   g.NB = (int)nb;
   const size_t zs = (size_t)M * g.TS;
-  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.HS + 3 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17 + 3 * PAIR_GROUP) * sizeof(double);
+  g.lds = (zs + PSI2_EXP_TAB + 2 * (size_t)g.RS + 2 * 16 * (size_t)g.HS + 3 * 16 * (size_t)g.OS + PAIR_WAVES * 16 * 17 + 3 * (size_t)group) * sizeof(double);
   return g.lds <= 160 * 1024;
 }
 
-// The pair form pays once a workgroup's 512 pairs are mostly real and every workgroup has a few dozen steps of 16 rows to walk.
+// The pair form pays once a workgroup's 512 or 640 pairs are mostly real and every workgroup has a few dozen steps of 16 rows to walk.
 // Measured against the sweep kernels at M = 100, Q = 40 / 40 / 20 (steps/s of the whole SVI step, pair : sweep):
 // 130432 rows 66.0 : 59.2, 65216 rows 128.9 : 109.7, 32608 rows 233 : 206, 16304 rows 395 : 370.  Smaller sizes were not measured.
 bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
