@@ -48,6 +48,7 @@ struct BigPlan {
   int sk;                                // K splits of the products that sum over the data rows
   int rows_blk;                          // workgroups of the row-gradient kernels
   int num_cu;                            // compute units of the device the plan was made for
+  bool pb; PairBlkGeom pbg;              // the psi2 term of the SVI bound runs in the pair form (rgp_psi2_pair.hip, blocked form)
 };
 
 static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
@@ -81,6 +82,7 @@ static BigPlan big_plan(rgp_handle h, int64_t N, int M, int Q) {
   p.sk = (int)(sk < 1 ? 1 : (sk > 256 ? 256 : sk));
   int64_t rb = (N + 3) / 4;
   p.rows_blk = (int)(rb < 1 ? 1 : (rb > 1024 ? 1024 : rb));
+  p.pb = p.QP <= RGP_MAX_QP && psi2_pairblk_selected(h, N, M, p.QP, p.Mld, p.pbg);
   return p;
 }
 
@@ -153,6 +155,7 @@ struct BigWs {
   int64_t *row_off, *own_pre, *up_pre;
   double *r2, *T2, *PsiR_part, *PsiR, *dYvar_row;     // collapsed bound only
   double* fp2_part; int frs;                            // psi2 forward on the matrix pipe: partial sums per row split, row splits
+  double *pb_ws, *pb_S22, *pb_DM, *pb_B_part, *pb_B1, *pb_B2, *pb_dz3;      // pair form of the psi2 term (bp_psi2)
 };
 
 static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, int D, int n_seq, BigWs& L, SviChain* ch,
@@ -203,6 +206,13 @@ static size_t big_carve(char* base, const BigPlan& p, int64_t N, int M, int Q, i
     if (rs > (N + 63) / 64) rs = (N + 63) / 64;
     L.frs = (int)(rs < 1 ? 1 : rs);
     L.fp2_part = ws.take<double>((size_t)L.frs * mm);
+  }
+  L.pb_ws = nullptr;
+  if (p.pb) {
+    L.pb_ws = ws.take<double>(psi2_pairblk_ws_doubles(p.pbg, N));
+    L.pb_S22 = ws.take<double>((size_t)N * p.W); L.pb_DM = ws.take<double>(nq);
+    L.pb_B_part = ws.take<double>((size_t)p.sk * M * QP);
+    L.pb_B1 = ws.take<double>((size_t)M * QP); L.pb_B2 = ws.take<double>((size_t)M * QP); L.pb_dz3 = ws.take<double>((size_t)M * QP);
   }
   if (vc) {
     vardtc_chain_carve(*vc, ws);
@@ -915,6 +925,39 @@ static rgp_status big_psi2_forward(rgp_handle h, hipStream_t s, const BigPlan& p
   return launch_big_psi2_fwd_mfma(h, s, N, M, L.zt, L.rt, L.dm, L.H, L.fp2_part, L.frs, psi2);
 }
 
+// The psi2 term of the SVI bound in the pair form (rgp_psi2_pair.hip, blocked form): forward sum and backward in one pass over
+// the unordered pairs of inducing rows on the matrix pipe, then, from v = V2 / 2 and T alone (as for wide windows,
+// rgp_wideq_impl.h):  [a1 | vz2 | w] = v [Z | Z^2 | 1],  B1 = v^T (d2 o mu),  B2 = v^T d2,  dZ2 = 2 B1 - Z o B2 - dZ3 and the row
+// gradients.  Outputs as launch_big_psi2_fwd + launch_big_psi2_bwd: L.psi2, row gradients added to L.gmu / L.gS, L.dz2, L.dlam2,
+// L.wsum2.
+static rgp_status bp_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, BigWs& L) {
+  const int QP = p.QP;
+  PairBlkOut o{};
+  o.psi2 = L.psi2; o.dz3 = L.pb_dz3;
+  rgp_status st = launch_psi2_pairblk(h, s, p.pbg, N, L.zt, L.rt, L.H, L.dLs, L.pb_ws, o);
+  if (st) return st;
+  hipLaunchKernelGGL(wq_dmu_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.rt.d2, L.rt.Xmu, L.pb_DM);
+  {
+    GemmArgs g;
+    g.m = (int)N; g.n = p.W; g.k = M; g.A = o.V2; g.lda = p.Mld; g.B = L.ZZ; g.ldb = p.W; g.C = L.pb_S22; g.ldc = p.W; g.alpha = 0.5;
+    launch_gemm(s, g);
+  }
+  for (int k = 0; k < 2; ++k) {
+    GemmArgs g;
+    g.m = M; g.n = QP; g.k = (int)N; g.A = o.V2; g.lda = p.Mld; g.ta = 1; g.B = k == 0 ? L.pb_DM : L.rt.d2; g.ldb = QP; g.alpha = 0.5;
+    g.C = L.pb_B_part; g.ldc = QP; g.splits = p.sk; g.split_stride = (int64_t)M * QP;
+    if (p.sk == 1) g.C = k == 0 ? L.pb_B1 : L.pb_B2;
+    launch_gemm(s, g);
+    if (p.sk > 1) launch_reduce(s, p.sk, (int64_t)M * QP, (int64_t)M * QP, L.pb_B_part, k == 0 ? L.pb_B1 : L.pb_B2, 1.0, 0);
+  }
+  hipLaunchKernelGGL(wq_dz2_kernel, dim3(big_nb256((int64_t)M * QP)), dim3(256), 0, s, M, QP, p.Mld, L.pb_B1, L.pb_B2, L.pb_dz3, L.zt.Zc, L.dz2);
+  hipLaunchKernelGGL(wq_rowgrad_kernel, dim3(p.rows_blk, (QP + 63) / 64), dim3(256), 0, s, N, Q, QP, p.W, L.pb_S22, o.T, L.rt.Xmu,
+                     L.rt.d2, L.zt.lam, L.gmu, L.gS, L.dlam2_part, L.wsum2_part);
+  const ReduceSeg segs[2] = {{L.dlam2_part, L.dlam2, p.rows_blk, QP, QP}, {L.wsum2_part, L.wsum2, p.rows_blk, 1, 1}};
+  launch_reduce_batch(s, 2, segs);
+  return RGP_OK;
+}
+
 static rgp_status big_check(rgp_handle h, int64_t N, int M, int Q, bool wide_ok = false) {
   if (N <= 0 || M <= 0 || Q <= 0) return rgp_fail(h, RGP_ERR_BAD_ARG, "N, M, Q must be positive");
   if (M > RGP_BIG_MAX_M) return rgp_fail(h, RGP_ERR_BAD_ARG, "M > 1024 is not supported by this build");
@@ -994,6 +1037,7 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
     hipLaunchKernelGGL(symmetrise_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
     if (L.wide) st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
+    else if (p.pb) st = bp_psi2(h, s, p, N, M, Q, L);
     else if (!(st = big_psi2_forward(h, s, p, N, M, L, L.psi2)))
       st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
     if (st) return st;
@@ -1091,6 +1135,10 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
   if (L.wide) {
     prof_begin(h, (double)N * M * M * Q);                     // rgp_get_profile times the whole GEMM-shaped psi2 term
     st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
+    prof_end(h);
+  } else if (p.pb) {
+    prof_begin(h, (double)N * M * M * Q);                     // rgp_get_profile times the whole fused psi2 term
+    st = bp_psi2(h, s, p, N, M, Q, L);
     prof_end(h);
   } else {
     st = big_psi2_forward(h, s, p, N, M, L, L.psi2);

@@ -243,7 +243,11 @@ extern "C" rgp_status rgp_set_psi2_pair(rgp_handle h, int mode) {
 }
 
 extern "C" int rgp_psi2_pair_would_run(rgp_handle h, int64_t N, int M, int Q) {
-  if (!h || N < 1 || M < 1 || Q < 1 || M > RGP_MAX_M || Q > RGP_MAX_QP) return 0;
+  if (!h || N < 1 || M < 1 || Q < 1 || Q > RGP_MAX_QP) return 0;
+  if (M > RGP_MAX_M) {                            // blocked layer step: the blocked form
+    PairBlkGeom gb;
+    return psi2_pairblk_selected(h, N, M, rgp_qp(Q), (M + 63) / 64 * 64, gb) ? 1 : 0;
+  }
   PairGeom g;
   return psi2_pair_selected(h, N, M, rgp_qp(Q), g) ? 1 : 0;
 }

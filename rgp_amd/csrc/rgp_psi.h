@@ -128,6 +128,24 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g);
 size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N);
 rgp_status launch_psi2_pair(rgp_handle h, const PairGeom& g, int64_t N, int Q, const ZTerms& zt, const RowTerms& rt,
                             const double* dLs, const Psi2Out& out, double* ws);
+// The pair form for 112 < M <= 1024 (blocked layer step): pair groups over 16 x 16 blocks of inducing rows, (group, row range)
+// tasks on one workgroup per CU.  h: the (row, m) part of the exponent [N][M] as the blocked psi1 forward pass leaves it.
+// Outputs: psi2 [M][M], dz3 [M][QP] (= sum_m' z[m',q] sum_n d2 W), and V2 = 2 v [N][Mld], T [N][QP] inside the workspace, from which
+// the caller forms the row gradients and the rest of dZ with matrix products.
+struct PairBlkGeom {
+  int M, QP, Mld, nb, NT, TG, ntl, G, RR, ntasks, grid, ND2;
+  int64_t ntiles;
+  size_t lds;
+};
+struct PairBlkOut {
+  double *psi2, *dz3;            // in: where to write
+  double *V2, *T;                // out: inside the workspace
+};
+bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g);
+bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g);
+size_t psi2_pairblk_ws_doubles(const PairBlkGeom& g, int64_t N);
+rgp_status launch_psi2_pairblk(rgp_handle h, hipStream_t s, const PairBlkGeom& g, int64_t N, const ZTerms& zt, const RowTerms& rt,
+                               const double* H, const double* dLs, double* ws, PairBlkOut& out);
 // out[i] = scale * sum_g part[g*stride + i], i < len (fixed order)
 void launch_reduce(hipStream_t s, int nblk, int64_t len, int64_t stride, const double* part, double* out, double scale,
                    int accumulate);

@@ -47,6 +47,7 @@ static constexpr int pair_nt(int QP) { return QP <= 20 ? PAIR_NT_NARROW : 4; }
 #define PAIR_WO0 1                // 1: waves 0-3 alone write the finished V2 / T tiles out and request the records
 #endif
 #define PAIR_GROUP_MAX (128 * 6)                     // pairs per workgroup at most (8 waves x NT tiles x 16)
+#define PAIR_LB 6                 // blocked form: column blocks of 16 inducing rows a pair group may touch
 
 static __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -85,6 +86,10 @@ struct PairArgs {
   const double *rec, *Zc, *lam, *dLs;
   double *PV, *Cpart, *p2_part;
   double* dbg;          // per-phase cycle stamps of a -DPAIR_STAMPS build (nullptr otherwise)
+  // blocked form (M > 112): h' in 16 x 16 blocks [tile][column block], outputs V2 [N][Mld], T [N][QP], C and pair sums in tile order
+  const double* Hq;
+  double *V2, *Tg, *Csum, *p2sum;
+  int nb, Mld, ntl, ntasks;
 };
 #ifdef PAIR_STAMPS
 // the counter reads are issued where the phases end and collected once per step: a read that was waited for on the spot would
@@ -114,9 +119,17 @@ struct PairArgs {
 // group of matrix instructions are requested before the current group is issued -- with scheduling barriers between the groups.
 #define PAIR_HS 112               // row stride of the h' and V2 tiles (= 16 mod 32: the four row groups of a wave on disjoint banks); M <= 112
 #define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
-template <int QP, int NT, bool role1>
-static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
+template <int QP, int NT, bool role1, bool BLK>
+static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a, const int gi, const int rr) {
   constexpr int KQ = QP / 4, QT = (QP + 15) / 16, ZS = 16 * QT + 1, TS = 16 * QT + 1, HS = PAIR_HS;
+  // Blocked form (BLK, M > 112).  The pair group's pairs live in at most PAIR_LB blocks of 16 inducing rows; the workgroup sees
+  // only those: "local" inducing row l = 16 * (local block) + (row in block), the Z image holds the local rows, and the h' and V2
+  // tiles are stored block by block, [local block][16 data rows][16], which is the order in which the h' blocks lie in memory
+  // (one LDS-DMA piece = 8 rows of a block).  Everything between the set-up and the write-out is the same code on local rows.
+  constexpr int ND2 = (16 * TS + 127) / 128;                                 // 1-KiB pieces of the d2 tile
+  constexpr int HR = BLK ? 16 : HS;                                          // row stride of the h' and V2 tiles
+  constexpr int VT = BLK ? PAIR_LB * 256 : 16 * HS;                          // length of a V2 tile
+  constexpr int HOFF = BLK ? ND2 * 128 : 16 * TS;                            // h' tile within the record
   constexpr int TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;       // T tile row stride: = 16 mod 32
   // Window columns of the C and T products: NF full tiles of 16 on v_mfma_f64_16x16x4 and NR groups of 4 on
   // v_mfma_f64_4x4x4_4b (four 4x4x4 blocks, a quarter of the cycles): no matrix instruction is spent on the padding of Q to 16.
@@ -124,9 +137,10 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   // w[row c][pair 4 kk + g]) and, as right operand, column c & 3 of the group at the row / pair g; its result lane holds
   // C[pair 4 (c >> 2) + g][column c & 3] resp. T[row 4 (c >> 2) + g][column c & 3].
   constexpr int NF = QP / 16, NR = (QP % 16) / 4, NF1 = NF > 0 ? NF : 1, NR1 = NR > 0 ? NR : 1, NE = NF + NR;
-  constexpr int RSP = (16 * (TS + HS) + 127) / 128 * 128;                    // record length: whole 1-KiB pieces
-  constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * 16 * HS, O_TB = O_TT + 3 * 16 * TT,
-                O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + 128 * NT, O_DL = O_PS + 128 * NT, O_Z = O_DL + 128 * NT;
+  constexpr int RSP = BLK ? ND2 * 128 + PAIR_LB * 256 : (16 * (TS + HS) + 127) / 128 * 128;    // record length: whole 1-KiB pieces
+  constexpr int O_ETAB = 0, O_INB = PSI2_EXP_TAB, O_V2 = O_INB + 2 * RSP, O_TT = O_V2 + 2 * VT, O_TB = O_TT + 3 * 16 * TT,
+                O_KP = O_TB + PAIR_WAVES * 16 * 17, O_PS = O_KP + 128 * NT, O_DL = O_PS + 128 * NT, O_Z = O_DL + 128 * NT,
+                O_TI = O_Z + PAIR_LB * 16 * ZS;                               // blocked form: tile table [8 NT] and block list [PAIR_LB] (ints)
   extern __shared__ double lds[];
   // LDS operands are addressed by their byte offset in the workgroup's LDS image: the kernel has no static LDS, so the dynamic
   // image starts at offset 0 and an offset is the whole address (no base register, no add in front of every access)
@@ -143,19 +157,26 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int tb = wave * NT;                                      // the wave's first tile within the pair group
-  const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
   const int64_t t0 = a.ntiles * rr / a.RR, t1 = a.ntiles * (rr + 1) / a.RR;
   const int nsteps = (int)(t1 - t0);
 
+  auto hcol = [](int p8) { return BLK ? (((p8 >> 7) << 11) | (p8 & 127)) : p8; };      // 8 l -> byte offset of column l in a tile row
+  int* const tinfo = (int*)(lds + O_TI);
+  int* const gbl = tinfo + 8 * NT;
   // record r of this workgroup -> LDS buffer r & 1, one 1-KiB piece per wave instruction
   // (inline asm: the compiler, unable to tell the DMA's LDS destination from the tiles the waves read meanwhile, would wait for
   // the transfer before the next LDS read; the waves wait for it themselves, with s_waitcnt vmcnt(0) in front of the barrier
   // that precedes the record's first use)
   auto request_record = [&](int r, int nw) {           // by waves 0 .. nw - 1
-    const double* src = a.rec + (size_t)(t0 + r) * RSP + lane * 2;
+    const double* src = a.rec + (size_t)(t0 + r) * (BLK ? ND2 * 128 : RSP) + lane * 2;
     const unsigned dst = (unsigned)(size_t)(inb + (r & 1) * RSP);
     for (int ch = wave; ch * 128 < RSP; ch += nw) {
       const double* gsrc = src + ch * 128;
+      if (BLK && ch >= ND2) {                            // h' block (ch - ND2) / 2 of the group's list, rows 0-7 or 8-15
+        int gbv = __builtin_amdgcn_readfirstlane(gbl[(ch - ND2) >> 1]);
+        if (gbv < 0) gbv = 0;                            // unused slot of the list: any block will do, nobody reads it
+        gsrc = a.Hq + ((size_t)(t0 + r) * a.nb + gbv) * 256 + ((ch - ND2) & 1) * 128 + lane * 2;
+      }
       const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + ch * 1024);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -165,12 +186,42 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #define PAIR_BARRIER() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 
   // ---- one-time set-up: Z image, exp table, zeroed output tiles, first two records, per-lane pair constants
-  for (int i = t; i < M * ZS; i += 512) {
-    const int m = i / ZS, q = i - m * ZS;
-    Zl[i] = (q < QP) ? a.Zc[(size_t)m * QP + q] : 0.0;
+  if (BLK) {
+    // Tile table of the group.  Tiles are numbered row by row over the upper triangle of the nb x nb grid of 16 x 16 blocks:
+    // block pair (I, I) has 9 tiles (diagonals d = 0 .. 8 of the block, the last one half full), (I, J > I) has 16; pair c of
+    // tile (I, J, d) is (16 I + c, 16 J + (c + d) mod 16): 16 different a and 16 different b, every unordered pair once.
+    if (t == 0) {
+      const int nb = a.nb;
+      for (int i = 0; i < PAIR_LB; ++i) gbl[i] = -1;
+      int I = 0, rem = gi * (8 * NT);
+      while (I < nb) { const int cnt = 9 + 16 * (nb - 1 - I); if (rem < cnt) break; rem -= cnt; ++I; }
+      int J = I, d = rem;
+      if (I < nb && rem >= 9) { J = I + 1 + (rem - 9) / 16; d = (rem - 9) % 16; }
+      int nl = 0;
+      for (int i = 0; i < 8 * NT; ++i) {
+        if (I >= nb) { tinfo[i] = 0; continue; }
+        int la = -1, lb = -1;
+        for (int j = 0; j < nl; ++j) { if (gbl[j] == I) la = j; if (gbl[j] == J) lb = j; }
+        if (la < 0) { la = nl < PAIR_LB ? nl++ : PAIR_LB - 1; gbl[la] = I; }     // (the host has checked that the list never overflows)
+        if (lb < 0) { if (J == I) lb = la; else { lb = nl < PAIR_LB ? nl++ : PAIR_LB - 1; gbl[lb] = J; } }
+        tinfo[i] = la | (lb << 3) | (d << 6) | ((I == J ? 1 : 0) << 10) | (1 << 11);
+        if (++d == (I == J ? 9 : 16)) { d = 0; if (++J == nb) { ++I; J = I; } }
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < PAIR_LB * 16 * ZS; i += 512) {
+      const int l = i / ZS, q = i - l * ZS;
+      const int gbv = gbl[l >> 4], m = gbv * 16 + (l & 15);
+      Zl[i] = (q < QP && gbv >= 0 && m < M) ? a.Zc[(size_t)m * QP + q] : 0.0;
+    }
+  } else {
+    for (int i = t; i < M * ZS; i += 512) {
+      const int m = i / ZS, q = i - m * ZS;
+      Zl[i] = (q < QP) ? a.Zc[(size_t)m * QP + q] : 0.0;
+    }
   }
   if (t < PSI2_EXP_TAB) etab[t] = exp2((double)t * (1.0 / PSI2_EXP_TAB));
-  for (int i = t; i < 2 * 16 * HS + 3 * 16 * TT; i += 512) v2b[i] = 0.0;
+  for (int i = t; i < 2 * VT + 3 * 16 * TT; i += 512) v2b[i] = 0.0;
   if (nsteps > 0) request_record(0, PAIR_WAVES);
   if (nsteps > 1) request_record(1, PAIR_WAVES);
   // per-lane constants: LDS byte offsets of this lane's operands (pair of tile k in the accumulator layout: column c), the
@@ -182,21 +233,37 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int tau = gi * (8 * NT) + tb + k;
-    int pa, pb;
-    const int p = 16 * tau + c;
-    pair_ab(p, M, a.P, pa, pb);
-    pvalid |= (p < a.P ? 1 : 0) << k;
-    pa8[k] = pa * 8; pb8[k] = pb * 8;
-    const double dlv = (p < a.P) ? a.dLs[(size_t)pa * M + pb] * (pa == pb ? 1.0 : 2.0) : 0.0;
-    double s = 0.0;
-    for (int q = 0; q < QP; ++q) s += a.lam[q] * a.Zc[(size_t)pa * QP + q] * a.Zc[(size_t)pb * QP + q];
-    if (g == 0) { LDSD(kpo + 128 * k) = 0.5 * s; LDSD(kpo + pso_d + 128 * k) = 0.0; LDSD(kpo + dlo_d + 128 * k) = dlv; }       // k_p
+    int pa, pb;                                                  // the lane's pair of the tile: rows of the Z image (local rows in the blocked form)
+    int ga, gb;                                                  // ... as inducing rows
+    bool ok;
     int w4[4];
+    if (BLK) {
+      const int ti = tinfo[tb + k];
+      const int la = ti & 7, lb = (ti >> 3) & 7, d = (ti >> 6) & 15;
+      pa = 16 * la + c; pb = 16 * lb + ((c + d) & 15);
+      ga = 16 * gbl[la] + c; gb = 16 * gbl[lb] + ((c + d) & 15);
+      ok = ((ti >> 11) & 1) && ga < M && gb < M && (!((ti >> 10) & 1) || d < 8 || c < 8);
+      if (!ok) { ga = 0; gb = 0; }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      pair_ab(16 * tau + 4 * kk + g, M, a.P, pa, pb);
-      w4[kk] = pa | (pb << 8);
+      for (int kk = 0; kk < 4; ++kk) w4[kk] = (16 * la + 4 * kk + g) | ((16 * lb + ((4 * kk + g + d) & 15)) << 8);
+    } else {
+      const int p = 16 * tau + c;
+      pair_ab(p, M, a.P, pa, pb);
+      ga = pa; gb = pb;
+      ok = p < a.P;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        int xa, xb;
+        pair_ab(16 * tau + 4 * kk + g, M, a.P, xa, xb);
+        w4[kk] = xa | (xb << 8);
+      }
     }
+    pvalid |= (ok ? 1 : 0) << k;
+    pa8[k] = pa * 8; pb8[k] = pb * 8;
+    const double dlv = ok ? a.dLs[(size_t)ga * M + gb] * (ga == gb ? 1.0 : 2.0) : 0.0;
+    double s = 0.0;
+    for (int q = 0; q < QP; ++q) s += a.lam[q] * a.Zc[(size_t)ga * QP + q] * a.Zc[(size_t)gb * QP + q];
+    if (g == 0) { LDSD(kpo + 128 * k) = 0.5 * s; LDSD(kpo + pso_d + 128 * k) = 0.0; LDSD(kpo + dlo_d + 128 * k) = dlv; }       // k_p
     pkt[k][0] = w4[0] | (w4[1] << 16);
     pkt[k][1] = w4[2] | (w4[3] << 16);
   }
@@ -223,7 +290,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 
   // write-out slice of this thread: row t / 32 of the tile, columns t % 32 + 32 j.  Few loop invariants on purpose: two LDS
   // offsets, one running pointer into the sums.
-  double* pvp = a.PV + ((size_t)t0 * 16 + (t >> 5)) * a.PW + (t & 31);     // row of tile k, advanced after B_k
+  double* pvp = BLK ? nullptr : a.PV + ((size_t)t0 * 16 + (t >> 5)) * a.PW + (t & 31);     // row of tile k, advanced after B_k
   int t3 = 2;                                                    // (k - 1) mod 3 at B_k
   // After barrier B_k: V2 tile k and T tile k - 1 are added to the global sums and cleared, record k + 2 is requested.
   // The write-out is the older waves' job (PAIR_WO0): they reach the barrier early whatever they are given (the hardware favours
@@ -234,6 +301,49 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     constexpr int NH = PAIR_WO0 ? 2 : 1;
     int tq = threadIdx.x;
     asm volatile("" : "+v"(tq));                                 // the slice's offsets are recomputed here, not kept across the step
+    if (BLK) {
+      // blocked form (threads 0-255 only, PAIR_WO0): V2 tile k is [local block][16 rows][16]; thread tq takes element tq of every
+      // block (row tq / 16, column tq % 16) to the block's columns of V2[N][Mld]; T tile k - 1 as below, to T[N][QP]
+      static_assert(!BLK || PAIR_WO0, "the blocked form's write-out is written for waves 0-3");
+      const int64_t row0 = (t0 + k) * 16;
+      const int64_t left = a.N - row0;
+      if (k < nsteps) {
+        double* const vt = v2b + (k & 1) * VT + tq;
+        const int row = tq >> 4;
+        double v[PAIR_LB];
+#pragma unroll
+        for (int j = 0; j < PAIR_LB; ++j) v[j] = vt[256 * j];
+        double* const dst = a.V2 + (row0 + row) * a.Mld + (tq & 15);
+#pragma unroll
+        for (int j = 0; j < PAIR_LB; ++j) {
+          vt[256 * j] = 0.0;
+          const int gbv = __builtin_amdgcn_readfirstlane(gbl[j]);
+          if (gbv >= 0 && row < left) atomicAdd(&dst[16 * gbv], v[j]);
+        }
+      }
+      if (k >= 1) {
+        const int wrow0 = tq >> 5, wcol = tq & 31;
+        const int tslots = (QP - wcol + 31) >> 5;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int wrow = wrow0 + 8 * h;
+          double* const trow = ttb + t3 * (16 * TT) + wrow * TT + wcol;
+          double* const prow = a.Tg + (row0 - 16 + wrow) * QP + wcol;
+          double v[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) v[j] = (j < tslots) ? trow[32 * j] : 0.0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j < tslots) {
+              trow[32 * j] = 0.0;
+              if (wrow < left + 16) atomicAdd(&prow[32 * j], v[j]);
+            }
+        }
+      }
+      t3 = (t3 == 2) ? 0 : t3 + 1;
+      if (k + 2 < nsteps) request_record(k + 2, 4);
+      return;
+    }
     const int wrow0 = tq >> 5, wcol = tq & 31;
     const int vslots = (a.M2 - wcol + 31) >> 5;                  // column slots of this thread in a V2 row (0..4)
     const int tslots = (QP - wcol + 31) >> 5;                    // ... in a T row (0..2)
@@ -283,8 +393,8 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
   int tt3 = 0;                                                   // s mod 3
   for (int s = 0; s < nsteps; ++s) {
     const int inB = (O_INB + (s & 1) * RSP) * 8;                 // d2 tile [16][TS] of this step's record
-    const int hB = inB + 16 * TS * 8;                            // h' tile [16][HS]
-    const int vB = (O_V2 + (s & 1) * (16 * HS)) * 8;             // V2 tile [16][HS]
+    const int hB = inB + HOFF * 8;                               // h' tile [16][HS]   (blocked form: [block][16][16])
+    const int vB = (O_V2 + (s & 1) * VT) * 8;                    // V2 tile, same shape
     const int tBs = (O_TT + tt3 * (16 * TT)) * 8;                // T tile [16][TT]
     tt3 = (tt3 == 2) ? 0 : tt3 + 1;
     // ======== GE(s) ========
@@ -296,7 +406,7 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     for (int k = 0; k < NT; ++k) { asm volatile("" : "+v"(pa8[k]), "+v"(pb8[k])); }      // the derived addresses are recomputed per step, not kept
     int c8, g8;
     lane8(c8, g8);
-    const int gH = g8 * HS, zc = O_Z * 8 + g8, aoff = c8 * TS + g8;
+    const int gH = g8 * HR, zc = O_Z * 8 + g8, aoff = c8 * TS + g8;
     d4 acc[NT];
     double A0, A1;
     int zoA[NT], zoB[NT];
@@ -307,10 +417,10 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
       for (int k = k0; k < k0 + 2 && k < NT; ++k) {
         kpv[k - k0] = LDSD(kpo + 128 * k);
-        int oa = pa8[k] + gH + hB, ob = pb8[k] + gH + hB;
+        int oa = hcol(pa8[k]) + gH + hB, ob = hcol(pb8[k]) + gH + hB;
         asm volatile("" : "+v"(oa), "+v"(ob));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { hA[k - k0][r] = LDSD(oa + r * (4 * HS * 8)); hBv[k - k0][r] = LDSD(ob + r * (4 * HS * 8)); }
+        for (int r = 0; r < 4; ++r) { hA[k - k0][r] = LDSD(oa + r * (4 * HR * 8)); hBv[k - k0][r] = LDSD(ob + r * (4 * HR * 8)); }
       }
       if (k0 + 2 >= NT) {                    // behind the last h' reads: the first Gram operands
 #pragma unroll
@@ -417,15 +527,15 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
     }
     // V2 adds in one batch (fire and forget: they drain under the C product)
     int gHv;
-    { int c8v, g8v; lane8(c8v, g8v); gHv = g8v * HS + vB; }
+    { int c8v, g8v; lane8(c8v, g8v); gHv = g8v * HR + vB; }
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-      int oa = pa8[k] + gHv, ob = pb8[k] + gHv;
+      int oa = hcol(pa8[k]) + gHv, ob = hcol(pb8[k]) + gHv;
       asm volatile("" : "+v"(oa), "+v"(ob));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        atomicAdd(LDSP(oa + r * (4 * HS * 8)), w[k][r]);
-        atomicAdd(LDSP(ob + r * (4 * HS * 8)), w[k][r]);
+        atomicAdd(LDSP(oa + r * (4 * HR * 8)), w[k][r]);
+        atomicAdd(LDSP(ob + r * (4 * HR * 8)), w[k][r]);
       }
     }
     PAIR_SB();
@@ -582,6 +692,19 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const int tau = gi * (8 * NT) + tb + k;
+    if (BLK) {                                    // the row ranges add into one array in tile order
+      if (tau >= a.ntl) continue;
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&a.Csum[((size_t)16 * tau + 4 * r + g) * QP + 16 * j + c], Cacc[k][j][r]);
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        atomicAdd(&a.Csum[((size_t)16 * tau + 4 * (c >> 2) + g) * QP + 16 * NF + 4 * j + (c & 3)], CaccR[k][j]);
+      const double psb = LDSD(kpo + pso_d + 128 * k);
+      if (g == 0 && ((pvalid >> k) & 1)) atomicAdd(&a.p2sum[16 * tau + c], psb);
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
       const int q = 16 * j + c;
@@ -603,8 +726,21 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a) {
 
 template <int QP>
 __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
-  if (threadIdx.x < 256) psi2_pair_body<QP, pair_nt(QP), false>(a);
-  else psi2_pair_body<QP, pair_nt(QP), true>(a);
+  const int gi = blockIdx.x % a.G, rr = blockIdx.x / a.G;
+  if (threadIdx.x < 256) psi2_pair_body<QP, pair_nt(QP), false, false>(a, gi, rr);
+  else psi2_pair_body<QP, pair_nt(QP), true, false>(a, gi, rr);
+}
+
+// Blocked form: the (pair group, row range) tasks outnumber the CUs; a workgroup takes every gridDim.x-th one.  Consecutive
+// tasks are the pair groups of one row range, so the workgroups running at any time share the range's records in L2.
+template <int QP>
+__global__ void __launch_bounds__(512, 2) psi2_pairblk_kernel(const PairArgs a) {
+  for (int task = blockIdx.x; task < a.ntasks; task += gridDim.x) {
+    const int gi = task % a.G, rr = task / a.G;
+    if (threadIdx.x < 256) psi2_pair_body<QP, pair_nt(QP), false, true>(a, gi, rr);
+    else psi2_pair_body<QP, pair_nt(QP), true, true>(a, gi, rr);
+    __syncthreads();                              // the next task's set-up overwrites the tables and tiles
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1047,5 +1183,198 @@ rgp_status launch_psi2_pair(rgp_handle h, const PairGeom& g, int64_t N, int Q, c
     default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (pair form): unsupported padded Q");
   }
   if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 (pair form) launch: ") + hipGetErrorString(e));
+  return RGP_OK;
+}
+
+// ==================================================================================================================
+// Blocked form for 112 < M <= 1024 (the blocked layer step, rgp_big_impl.h): the same main kernel over pair groups that
+// touch at most PAIR_LB blocks of 16 inducing rows each.  Its outputs are V2 [N][Mld] and T [N][QP] (sums over pairs, added by the
+// groups with global atomics), C [tile order][QP] and the pair sums of psi2 [tile order] (sums over rows, added by the row ranges);
+// the caller finishes the row gradients and dZ from those with matrix products, as for wide windows.
+// ==================================================================================================================
+// slot 16 tau + c of the unordered pair (a, b) in the tile order of the main kernel's set-up
+static __host__ __device__ inline int pairblk_slot(int a, int b, int nb) {
+  int Ia = a >> 4, Ib = b >> 4, ca = a & 15, cb = b & 15;
+  int I, J, c, d;
+  if (Ia == Ib) {
+    I = J = Ia;
+    const int diff = (cb - ca) & 15;
+    if (diff < 8) { d = diff; c = ca; }
+    else if (diff > 8) { d = 16 - diff; c = cb; }
+    else { d = 8; c = ca < cb ? ca : cb; }
+  } else {
+    if (Ia > Ib) { int x = Ia; Ia = Ib; Ib = x; x = ca; ca = cb; cb = x; }
+    I = Ia; J = Ib; c = ca; d = (cb - ca) & 15;
+  }
+  const int S = 9 * I + 16 * (I * (nb - 1) - I * (I - 1) / 2);
+  const int tau = S + (J == I ? d : 9 + 16 * (J - I - 1) + d);
+  return 16 * tau + c;
+}
+
+// Records of the blocked form, one per tile of 16 data rows: rec [tile][ND2 x 128] = -d2 / 2 as [16][TS], zero padded;
+// Hq [tile][column block][16 rows][16] = h[n,m] + g0[n] / 2 (h: the (row, m) part of the exponent as the blocked psi1 forward pass
+// leaves it, [N][M]); rows beyond N get -inf (their exponentials are 0), columns beyond M get 0.  Also zeroes every array the main
+// kernel adds into.
+template <int QP>
+__global__ void __launch_bounds__(256) psi2_pairblk_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int nb,
+                                                                 const int Mld, const double* __restrict__ d2,
+                                                                 const double* __restrict__ g0, const double* __restrict__ H,
+                                                                 double* __restrict__ rec, double* __restrict__ Hq,
+                                                                 double* __restrict__ V2, double* __restrict__ T,
+                                                                 double* __restrict__ Csum, const int64_t ncs,
+                                                                 double* __restrict__ p2sum, const int64_t np2) {
+  constexpr int QT = (QP + 15) / 16, TS = 16 * QT + 1, ND2 = (16 * TS + 127) / 128;
+  const int t = threadIdx.x;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < ncs; i += (int64_t)gridDim.x * 256) Csum[i] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < np2; i += (int64_t)gridDim.x * 256) p2sum[i] = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * 16;
+    double* const r = rec + (size_t)tile * (ND2 * 128);
+    for (int i = t; i < ND2 * 128; i += 256) {
+      const int row = i / TS, col = i - row * TS;
+      const int64_t n = n0 + row;
+      r[i] = (row < 16 && col < QP && n < N) ? -0.5 * d2[(size_t)n * QP + col] : 0.0;
+    }
+    double* const hq = Hq + (size_t)tile * nb * 256;
+    for (int i = t; i < nb * 256; i += 256) {
+      const int blk = i >> 8, row = (i >> 4) & 15, m = 16 * blk + (i & 15);
+      const int64_t n = n0 + row;
+      hq[i] = (n < N) ? ((m < M) ? H[(size_t)n * M + m] + 0.5 * g0[n] : 0.0) : -INFINITY;
+    }
+    const int64_t rows = (N - n0 < 16) ? N - n0 : 16;
+    for (int64_t i = t; i < rows * Mld; i += 256) V2[n0 * Mld + i] = 0.0;
+    for (int64_t i = t; i < rows * QP; i += 256) T[n0 * QP + i] = 0.0;
+  }
+}
+
+// psi2[a,b] = psi2[b,a] = pair sum;  dZ3[m,q] = sum_m' z[m',q] sum_n d2[n,q] W[n,m,m'] from the C sums (taken over -d2 / 2 with
+// c_p = 2 off the diagonal in the weights)
+__global__ void __launch_bounds__(256) psi2_pairblk_sym_kernel(const int M, const int nb, const double* __restrict__ p2sum,
+                                                                double* __restrict__ psi2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * M) return;
+  const int a = i / M, b = i - a * M;
+  psi2[i] = p2sum[pairblk_slot(a, b, nb)];
+}
+__global__ void __launch_bounds__(256) psi2_pairblk_dz3_kernel(const int M, const int QP, const int nb, const double* __restrict__ Csum,
+                                                                const double* __restrict__ Zc, double* __restrict__ dz3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * QP) return;
+  const int m = i / QP, q = i - m * QP;         // consecutive threads walk q: coalesced reads of C
+  double s = 0.0;
+#pragma unroll 4
+  for (int mp = 0; mp < M; ++mp) {
+    const double cv = Csum[(size_t)pairblk_slot(m, mp, nb) * QP + q];
+    s += Zc[(size_t)mp * QP + q] * (mp == m ? cv : 0.5 * cv);
+  }
+  dz3[i] = -2.0 * s;
+}
+
+bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g) {
+  if (M <= 112 || M > 1024 || QP < 8 || QP > RGP_MAX_QP || (QP & 3) || N < 1) return false;
+  g.M = M; g.QP = QP; g.Mld = Mld;
+  g.nb = (M + 15) / 16;
+  if (Mld < 16 * g.nb) return false;
+  g.NT = pair_nt(QP);
+  g.TG = 8 * g.NT;
+  g.ntl = 9 * g.nb + 8 * g.nb * (g.nb - 1);
+  g.G = (g.ntl + g.TG - 1) / g.TG;
+  {                                               // the block list of every group must fit: walk the tile order as the kernel does
+    int I = 0, J = 0, d = 0;
+    for (int gi = 0; gi < g.G; ++gi) {
+      int list[2 * PAIR_GROUP_MAX / 16], nl = 0;
+      for (int i = 0; i < g.TG && I < g.nb; ++i) {
+        bool fa = false, fb = false;
+        for (int j = 0; j < nl; ++j) { fa |= list[j] == I; fb |= list[j] == J; }
+        if (!fa) list[nl++] = I;
+        if (!fb && J != I) list[nl++] = J;
+        if (++d == (I == J ? 9 : 16)) { d = 0; if (++J == g.nb) { ++I; J = I; } }
+      }
+      if (nl > PAIR_LB) return false;
+    }
+  }
+  g.ntiles = (N + 15) / 16;
+  // row ranges: a task should walk a few hundred steps (its set-up and its flush of 512 x QP sums are then negligible), and the
+  // tasks should fill the last round of workgroups
+  const int cu = h->num_cu > 0 ? h->num_cu : 256;
+  int64_t rmax = g.ntiles / 256;
+  if (rmax < 1) rmax = 1;
+  if (rmax > 64) rmax = 64;
+  int best = (int)rmax;
+  double bfill = 0.0;
+  for (int64_t r = rmax; r >= (rmax + 1) / 2; --r) {
+    const int64_t tasks = (int64_t)g.G * r, rounds = (tasks + cu - 1) / cu;
+    const double fill = (double)tasks / (double)(rounds * cu);
+    if (fill > bfill + 1e-9) { bfill = fill; best = (int)r; }
+  }
+  g.RR = best;
+  g.ntasks = g.G * g.RR;
+  g.grid = g.ntasks < cu ? g.ntasks : cu;
+  const int QT = (QP + 15) / 16, TS = 16 * QT + 1, ZS = TS, TT = ((16 * QT) % 32 == 16) ? 16 * QT : 16 * QT + 16;
+  g.ND2 = (16 * TS + 127) / 128;
+  const size_t dbl = PSI2_EXP_TAB + 2 * (size_t)(g.ND2 * 128 + PAIR_LB * 256) + 2 * (size_t)PAIR_LB * 256 + 3 * 16 * (size_t)TT +
+                     PAIR_WAVES * 16 * 17 + 3 * 128 * (size_t)g.NT + (size_t)PAIR_LB * 16 * ZS + (8 * g.NT + PAIR_LB + 1) / 2;
+  g.lds = dbl * sizeof(double);
+  return g.lds <= 160 * 1024;
+}
+
+// Measured against the blocked forward + backward sweep kernels: see psi2_pair_selected for the mode; the blocked form is
+// chosen from 4096 rows.
+bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g) {
+  int mode = h->psi2_pair;
+  if (mode < 0) {
+    static int env_mode = -2;
+    if (env_mode == -2) { const char* e = getenv("RGP_PSI2_PAIR"); env_mode = e ? atoi(e) : PAIR_DEFAULT_MODE; }
+    mode = env_mode;
+  }
+  if (mode <= 0 || h->deterministic) return false;
+  if (!psi2_pairblk_geom(h, N, M, QP, Mld, g)) return false;
+  if (mode >= 2) return true;
+  return N >= 4096;
+}
+
+static inline size_t pb_r(size_t n) { return (n + 31) & ~(size_t)31; }
+size_t psi2_pairblk_ws_doubles(const PairBlkGeom& g, int64_t N) {
+  return pb_r((size_t)g.ntiles * g.ND2 * 128) + pb_r((size_t)g.ntiles * g.nb * 256) + pb_r((size_t)N * g.Mld) + pb_r((size_t)N * g.QP) +
+         pb_r((size_t)g.G * g.TG * 16 * g.QP) + pb_r((size_t)g.G * g.TG * 16) + 64;
+}
+
+template <int QP>
+static hipError_t pairblk_launch(hipStream_t s, const PairBlkGeom& g, int64_t N, const ZTerms& zt, const RowTerms& rt, const double* H,
+                                 const double* dLs, double* ws, PairBlkOut& o, int num_cu) {
+  double* rec = ws;
+  double* Hq = rec + pb_r((size_t)g.ntiles * g.ND2 * 128);
+  double* V2 = Hq + pb_r((size_t)g.ntiles * g.nb * 256);
+  double* T = V2 + pb_r((size_t)N * g.Mld);
+  double* Csum = T + pb_r((size_t)N * g.QP);
+  double* p2sum = Csum + pb_r((size_t)g.G * g.TG * 16 * g.QP);
+  const int64_t ncs = (int64_t)g.G * g.TG * 16 * QP, np2 = (int64_t)g.G * g.TG * 16;
+  int64_t pg = g.ntiles < 4 * (int64_t)num_cu ? g.ntiles : 4 * (int64_t)num_cu;
+  if (pg < 1) pg = 1;
+  hipLaunchKernelGGL((psi2_pairblk_prep_kernel<QP>), dim3((unsigned)pg), dim3(256), 0, s, N, g.ntiles, g.M, g.nb, g.Mld, rt.d2, rt.g0, H, rec,
+                     Hq, V2, T, Csum, ncs, p2sum, np2);
+  PairArgs a{};
+  a.N = N; a.ntiles = g.ntiles; a.M = g.M; a.G = g.G; a.RR = g.RR;
+  a.rec = rec; a.Zc = zt.Zc; a.lam = zt.lam; a.dLs = dLs;
+  a.Hq = Hq; a.V2 = V2; a.Tg = T; a.Csum = Csum; a.p2sum = p2sum; a.nb = g.nb; a.Mld = g.Mld; a.ntl = g.ntl; a.ntasks = g.ntasks;
+  hipError_t e = hipFuncSetAttribute((const void*)psi2_pairblk_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((psi2_pairblk_kernel<QP>), dim3(g.grid), dim3(512), g.lds, s, a);
+  hipLaunchKernelGGL(psi2_pairblk_sym_kernel, dim3((g.M * g.M + 255) / 256), dim3(256), 0, s, g.M, g.nb, p2sum, o.psi2);
+  hipLaunchKernelGGL(psi2_pairblk_dz3_kernel, dim3((g.M * QP + 255) / 256), dim3(256), 0, s, g.M, QP, g.nb, Csum, zt.Zc, o.dz3);
+  o.V2 = V2; o.T = T;
+  return hipGetLastError();
+}
+
+rgp_status launch_psi2_pairblk(rgp_handle h, hipStream_t s, const PairBlkGeom& g, int64_t N, const ZTerms& zt, const RowTerms& rt,
+                               const double* H, const double* dLs, double* ws, PairBlkOut& out) {
+  hipError_t e = hipSuccess;
+  switch (g.QP) {
+#define PBL(qp) case qp: e = pairblk_launch<qp>(s, g, N, zt, rt, H, dLs, ws, out, h->num_cu); break;
+    PBL(8) PBL(16) PBL(20) PBL(24) PBL(32) PBL(40) PBL(48) PBL(56) PBL(64)
+#undef PBL
+    default: return rgp_fail(h, RGP_ERR_BAD_ARG, "psi2 (pair form, blocked): unsupported padded Q");
+  }
+  if (e != hipSuccess) return rgp_fail(h, RGP_ERR_HIP, std::string("psi2 (pair form, blocked) launch: ") + hipGetErrorString(e));
   return RGP_OK;
 }
