@@ -223,10 +223,22 @@ def main():
                 tnote = 'bytes per Q=40 launch from separate rocprofv3 --pmc passes (profiles/r2_psi2_rowsP_traffic_raw.json); algorithmic ~0.27e9'
         else:
             metric = 'SVI steps/sec, 3-layer RGP M=500 T=65536 D=64 (BASELINE config 5; ELBO rel-err vs CPU oracle: elbo_rel_err_vs_oracle)'
-            kernel = ('big_psi2_bwd_kernel (psi2 backward sweep over inducing blocks, fp64 VALU, 4 launches per step: Q=40,40,40,20); the '
-                      'forward sums run in big_psi2_fwd_kernel (another 2*N*M*M*Q flop on 56 % of the pairs, not counted here)')
-            traffic = measured_traffic_bytes('r2_cfg5_psi2_bwd_traffic_raw.json')
-            tnote = 'bytes per Q=40 launch from a separate rocprofv3 --pmc pass (profiles/r2_cfg5_psi2_bwd_traffic_raw.json)'
+            rows = mb_loc * (T - cfg['U_win'])
+            pair = m.handle.psi2_pair_would_run(rows, cfg['M'], 2 * cfg['U_win'])
+            if pair:
+                kernel = ('psi2 term in the pair form, blocked: psi2_pairblk_prep_kernel + psi2_pairblk_kernel (v_mfma_f64_16x16x4 over the '
+                          'unordered pairs of inducing rows in groups over 16 x 16 blocks; forward sums and backward in one pass) + '
+                          'the products that finish the row gradients and dZ on the GEMM kernel; the time is that of the whole term, '
+                          '4 per step: Q=40,40,40,20')
+                traffic = measured_traffic_bytes('r3_cfg5_pairblk_traffic_raw.json')
+                tnote = ('bytes per Q=40 term (record, main kernel and the kernels behind it) from separate rocprofv3 --pmc passes '
+                         '(profiles/r3_cfg5_pairblk_traffic_raw.json); most of it is the fp64 atomic adds of the 257 pair groups into V2 and T '
+                         'and their reads of the h blocks and d2 records')
+            else:
+                kernel = ('big_psi2_bwd_kernel (psi2 backward sweep over inducing blocks, fp64 VALU, 4 launches per step: Q=40,40,40,20); the '
+                          'forward sums run in big_psi2_fwd_kernel (another 2*N*M*M*Q flop on 56 % of the pairs, not counted here)')
+                traffic = measured_traffic_bytes('r2_cfg5_psi2_bwd_traffic_raw.json')
+                tnote = 'bytes per Q=40 launch from a separate rocprofv3 --pmc pass (profiles/r2_cfg5_psi2_bwd_traffic_raw.json)'
         out = {
             'metric': metric,
             'value': steps / dt, 'unit': 'SVI steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -244,7 +256,7 @@ def main():
                                                         'is three large matrix products' if a.wide else
                                                         'fp64 MFMA (v_mfma_f64_16x16x4) for the three products of the pair form; the exponentials and '
                                                         'operand products between them are fp64 VALU on the same pipe (costs add, '
-                                                        'profiles/r3_mfma_probes.txt)' if (a.config == 4 and pair) else
+                                                        'profiles/r3_mfma_probes.txt)' if pair else
                                                         'fp64 VALU: the contract offers hbm|mfma; on MI355X the fp64 matrix pipe shares the vector '
                                                         'pipe\'s datapath and is slower (profiles/r1_f64_peak.txt), so the contraction runs as v_fma_f64',
                          'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -259,6 +271,9 @@ def main():
                                   'earlier rounds; the pair form executes 3*N*M*(M+1)*Q (1.60e11 per Q=40 pass, '
                                   'SQ_INSTS_VALU_MFMA_MOPS_F64 in profiles/r3_psi2_pair_counters.json) on the matrix pipe, which is busy 48 % '
                                   'of the main kernel\'s time') if (a.config == 4 and pair) else
+                                 ('flop = 4*N*M*M*Q per psi2 term, the count of the dense factorised backward form, kept so that the fraction '
+                                  'compares with earlier rounds; the pair form executes 3*N*M*(M+1)*Q plus 5 % of padded pairs on the matrix '
+                                  'pipe and yields the forward sums as well (the sweep kernels spent another 2*N*M*M*Q on those)') if pair else
                                  ('flop = 4*N*M*M*Q per launch (Gram + W.z products of the factorised form); the N*M*M fp64 exp '
                                   'evaluations are extra VALU work not counted; the unfactorised GPy form would count 10*N*M*M*Q')},
         }

@@ -133,7 +133,7 @@ rgp_status launch_psi2_pair(rgp_handle h, const PairGeom& g, int64_t N, int Q, c
 // Outputs: psi2 [M][M], dz3 [M][QP] (= sum_m' z[m',q] sum_n d2 W), and V2 = 2 v [N][Mld], T [N][QP] inside the workspace, from which
 // the caller forms the row gradients and the rest of dZ with matrix products.
 struct PairBlkGeom {
-  int M, QP, Mld, nb, NT, TG, ntl, G, RR, ntasks, grid, ND2;
+  int M, QP, Mld, nb, rem, NT, TG, ntl, G, RR, ntasks, grid, ND2;
   int64_t ntiles;
   size_t lds;
 };

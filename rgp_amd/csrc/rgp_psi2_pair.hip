@@ -89,7 +89,7 @@ struct PairArgs {
   // blocked form (M > 112): h' in 16 x 16 blocks [tile][column block], outputs V2 [N][Mld], T [N][QP], C and pair sums in tile order
   const double* Hq;
   double *V2, *Tg, *Csum, *p2sum;
-  int nb, Mld, ntl, ntasks;
+  int nb, Mld, ntl, ntasks, rem;          // rem: inducing rows in the last block of 16 (1 .. 16)
 };
 #ifdef PAIR_STAMPS
 // the counter reads are issued where the phases end and collected once per step: a read that was waited for on the spot would
@@ -190,13 +190,18 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a, const i
     // Tile table of the group.  Tiles are numbered row by row over the upper triangle of the nb x nb grid of 16 x 16 blocks:
     // block pair (I, I) has 9 tiles (diagonals d = 0 .. 8 of the block, the last one half full), (I, J > I) has 16; pair c of
     // tile (I, J, d) is (16 I + c, 16 J + (c + d) mod 16): 16 different a and 16 different b, every unordered pair once.
+    // The last block column may hold fewer than 16 inducing rows (a.rem): (I, nb - 1) then has a.rem tiles, pair c of tile d being
+    // (16 I + c, 16 (nb - 1) + (c + d) mod rem) -- no tile is spent on rows that do not exist.
     if (t == 0) {
       const int nb = a.nb;
       for (int i = 0; i < PAIR_LB; ++i) gbl[i] = -1;
       int I = 0, rem = gi * (8 * NT);
-      while (I < nb) { const int cnt = 9 + 16 * (nb - 1 - I); if (rem < cnt) break; rem -= cnt; ++I; }
+      while (I < nb) { const int cnt = I < nb - 1 ? 9 + 16 * (nb - 2 - I) + a.rem : 9; if (rem < cnt) break; rem -= cnt; ++I; }
       int J = I, d = rem;
-      if (I < nb && rem >= 9) { J = I + 1 + (rem - 9) / 16; d = (rem - 9) % 16; }
+      if (I < nb && rem >= 9) {
+        const int x = rem - 9, full = 16 * (nb - 2 - I);
+        if (x < full) { J = I + 1 + x / 16; d = x % 16; } else { J = nb - 1; d = x - full; }
+      }
       int nl = 0;
       for (int i = 0; i < 8 * NT; ++i) {
         if (I >= nb) { tinfo[i] = 0; continue; }
@@ -204,8 +209,8 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a, const i
         for (int j = 0; j < nl; ++j) { if (gbl[j] == I) la = j; if (gbl[j] == J) lb = j; }
         if (la < 0) { la = nl < PAIR_LB ? nl++ : PAIR_LB - 1; gbl[la] = I; }     // (the host has checked that the list never overflows)
         if (lb < 0) { if (J == I) lb = la; else { lb = nl < PAIR_LB ? nl++ : PAIR_LB - 1; gbl[lb] = J; } }
-        tinfo[i] = la | (lb << 3) | (d << 6) | ((I == J ? 1 : 0) << 10) | (1 << 11);
-        if (++d == (I == J ? 9 : 16)) { d = 0; if (++J == nb) { ++I; J = I; } }
+        tinfo[i] = la | (lb << 3) | (d << 6) | ((I == J ? 1 : 0) << 10) | (1 << 11) | ((J == nb - 1 && I != J ? 1 : 0) << 12);
+        if (++d == (I == J ? 9 : (J == nb - 1 ? a.rem : 16))) { d = 0; if (++J == nb) { ++I; J = I; } }
       }
     }
     __syncthreads();
@@ -240,12 +245,13 @@ static __device__ __forceinline__ void psi2_pair_body(const PairArgs& a, const i
     if (BLK) {
       const int ti = tinfo[tb + k];
       const int la = ti & 7, lb = (ti >> 3) & 7, d = (ti >> 6) & 15;
-      pa = 16 * la + c; pb = 16 * lb + ((c + d) & 15);
-      ga = 16 * gbl[la] + c; gb = 16 * gbl[lb] + ((c + d) & 15);
+      const int md = ((ti >> 12) & 1) ? a.rem : 16;             // rows of the b block
+      pa = 16 * la + c; pb = 16 * lb + (c + d) % md;
+      ga = 16 * gbl[la] + c; gb = 16 * gbl[lb] + (c + d) % md;
       ok = ((ti >> 11) & 1) && ga < M && gb < M && (!((ti >> 10) & 1) || d < 8 || c < 8);
       if (!ok) { ga = 0; gb = 0; }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w4[kk] = (16 * la + 4 * kk + g) | ((16 * lb + ((4 * kk + g + d) & 15)) << 8);
+      for (int kk = 0; kk < 4; ++kk) w4[kk] = (16 * la + 4 * kk + g) | ((16 * lb + (4 * kk + g + d) % md) << 8);
     } else {
       const int p = 16 * tau + c;
       pair_ab(p, M, a.P, pa, pb);
@@ -1193,7 +1199,7 @@ rgp_status launch_psi2_pair(rgp_handle h, const PairGeom& g, int64_t N, int Q, c
 // the caller finishes the row gradients and dZ from those with matrix products, as for wide windows.
 // ==================================================================================================================
 // slot 16 tau + c of the unordered pair (a, b) in the tile order of the main kernel's set-up
-static __host__ __device__ inline int pairblk_slot(int a, int b, int nb) {
+static __host__ __device__ inline int pairblk_slot(int a, int b, int nb, int rem) {
   int Ia = a >> 4, Ib = b >> 4, ca = a & 15, cb = b & 15;
   int I, J, c, d;
   if (Ia == Ib) {
@@ -1204,9 +1210,10 @@ static __host__ __device__ inline int pairblk_slot(int a, int b, int nb) {
     else { d = 8; c = ca < cb ? ca : cb; }
   } else {
     if (Ia > Ib) { int x = Ia; Ia = Ib; Ib = x; x = ca; ca = cb; cb = x; }
-    I = Ia; J = Ib; c = ca; d = (cb - ca) & 15;
+    I = Ia; J = Ib; c = ca;
+    d = (J == nb - 1) ? ((cb - ca) % rem + rem) % rem : (cb - ca) & 15;
   }
-  const int S = 9 * I + 16 * (I * (nb - 1) - I * (I - 1) / 2);
+  const int S = 9 * I + 16 * (I * (nb - 2) - I * (I - 1) / 2) + rem * I;       // tiles of the block rows before I
   const int tau = S + (J == I ? d : 9 + 16 * (J - I - 1) + d);
   return 16 * tau + c;
 }
@@ -1249,14 +1256,14 @@ __global__ void __launch_bounds__(256) psi2_pairblk_prep_kernel(const int64_t N,
 
 // psi2[a,b] = psi2[b,a] = pair sum;  dZ3[m,q] = sum_m' z[m',q] sum_n d2[n,q] W[n,m,m'] from the C sums (taken over -d2 / 2 with
 // c_p = 2 off the diagonal in the weights)
-__global__ void __launch_bounds__(256) psi2_pairblk_sym_kernel(const int M, const int nb, const double* __restrict__ p2sum,
+__global__ void __launch_bounds__(256) psi2_pairblk_sym_kernel(const int M, const int nb, const int rem, const double* __restrict__ p2sum,
                                                                 double* __restrict__ psi2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * M) return;
   const int a = i / M, b = i - a * M;
-  psi2[i] = p2sum[pairblk_slot(a, b, nb)];
+  psi2[i] = p2sum[pairblk_slot(a, b, nb, rem)];
 }
-__global__ void __launch_bounds__(256) psi2_pairblk_dz3_kernel(const int M, const int QP, const int nb, const double* __restrict__ Csum,
+__global__ void __launch_bounds__(256) psi2_pairblk_dz3_kernel(const int M, const int QP, const int nb, const int rem, const double* __restrict__ Csum,
                                                                 const double* __restrict__ Zc, double* __restrict__ dz3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * QP) return;
@@ -1264,7 +1271,7 @@ __global__ void __launch_bounds__(256) psi2_pairblk_dz3_kernel(const int M, cons
   double s = 0.0;
 #pragma unroll 4
   for (int mp = 0; mp < M; ++mp) {
-    const double cv = Csum[(size_t)pairblk_slot(m, mp, nb) * QP + q];
+    const double cv = Csum[(size_t)pairblk_slot(m, mp, nb, rem) * QP + q];
     s += Zc[(size_t)mp * QP + q] * (mp == m ? cv : 0.5 * cv);
   }
   dz3[i] = -2.0 * s;
@@ -1277,7 +1284,8 @@ bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkG
   if (Mld < 16 * g.nb) return false;
   g.NT = pair_nt(QP);
   g.TG = 8 * g.NT;
-  g.ntl = 9 * g.nb + 8 * g.nb * (g.nb - 1);
+  g.rem = M - 16 * (g.nb - 1);
+  g.ntl = 9 * g.nb + 8 * (g.nb - 1) * (g.nb - 2) + g.rem * (g.nb - 1);
   g.G = (g.ntl + g.TG - 1) / g.TG;
   {                                               // the block list of every group must fit: walk the tile order as the kernel does
     int I = 0, J = 0, d = 0;
@@ -1288,7 +1296,7 @@ bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkG
         for (int j = 0; j < nl; ++j) { fa |= list[j] == I; fb |= list[j] == J; }
         if (!fa) list[nl++] = I;
         if (!fb && J != I) list[nl++] = J;
-        if (++d == (I == J ? 9 : 16)) { d = 0; if (++J == g.nb) { ++I; J = I; } }
+        if (++d == (I == J ? 9 : (J == g.nb - 1 ? g.rem : 16))) { d = 0; if (++J == g.nb) { ++I; J = I; } }
       }
       if (nl > PAIR_LB) return false;
     }
@@ -1298,8 +1306,13 @@ bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkG
   // tasks should fill the last round of workgroups
   const int cu = h->num_cu > 0 ? h->num_cu : 256;
   int64_t rmax = g.ntiles / 256;
-  if (rmax < 1) rmax = 1;
   if (rmax > 64) rmax = 64;
+  {                                               // few pair groups (small M): shorter tasks, down to 24 steps, until every CU has two
+    int64_t rfill = 2 * ((cu + g.G - 1) / g.G), rcap = g.ntiles / 24;
+    if (rfill > rcap) rfill = rcap;
+    if (rmax < rfill) rmax = rfill;
+  }
+  if (rmax < 1) rmax = 1;
   int best = (int)rmax;
   double bfill = 0.0;
   for (int64_t r = rmax; r >= (rmax + 1) / 2; --r) {
@@ -1318,8 +1331,10 @@ bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkG
   return g.lds <= 160 * 1024;
 }
 
-// Measured against the blocked forward + backward sweep kernels: see psi2_pair_selected for the mode; the blocked form is
-// chosen from 4096 rows.
+// Measured against the blocked forward + backward sweep kernels through rgp_psi_backward (tools/pairblk_ab.py; ms per call,
+// sweeps : pair form): M = 500, Q = 40: 1024 rows 2.2 : 1.9, 4096 rows 6.4 : 5.2, 16384 rows 23.5 : 15.4, 65536 rows 93.5 : 50.4;
+// M = 200: 1024 rows 0.58 : 0.80, 2048 rows 0.95 : 0.76, 65536 rows 20.4 : 9.6; M = 1000: 1.4x at 512 rows, 2.1x at 16384.
+// The blocked form is chosen from 2048 rows.
 bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g) {
   int mode = h->psi2_pair;
   if (mode < 0) {
@@ -1330,7 +1345,7 @@ bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, Pair
   if (mode <= 0 || h->deterministic) return false;
   if (!psi2_pairblk_geom(h, N, M, QP, Mld, g)) return false;
   if (mode >= 2) return true;
-  return N >= 4096;
+  return N >= 2048;
 }
 
 static inline size_t pb_r(size_t n) { return (n + 31) & ~(size_t)31; }
@@ -1356,12 +1371,12 @@ static hipError_t pairblk_launch(hipStream_t s, const PairBlkGeom& g, int64_t N,
   PairArgs a{};
   a.N = N; a.ntiles = g.ntiles; a.M = g.M; a.G = g.G; a.RR = g.RR;
   a.rec = rec; a.Zc = zt.Zc; a.lam = zt.lam; a.dLs = dLs;
-  a.Hq = Hq; a.V2 = V2; a.Tg = T; a.Csum = Csum; a.p2sum = p2sum; a.nb = g.nb; a.Mld = g.Mld; a.ntl = g.ntl; a.ntasks = g.ntasks;
+  a.Hq = Hq; a.V2 = V2; a.Tg = T; a.Csum = Csum; a.p2sum = p2sum; a.nb = g.nb; a.Mld = g.Mld; a.ntl = g.ntl; a.ntasks = g.ntasks; a.rem = g.rem;
   hipError_t e = hipFuncSetAttribute((const void*)psi2_pairblk_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((psi2_pairblk_kernel<QP>), dim3(g.grid), dim3(512), g.lds, s, a);
-  hipLaunchKernelGGL(psi2_pairblk_sym_kernel, dim3((g.M * g.M + 255) / 256), dim3(256), 0, s, g.M, g.nb, p2sum, o.psi2);
-  hipLaunchKernelGGL(psi2_pairblk_dz3_kernel, dim3((g.M * QP + 255) / 256), dim3(256), 0, s, g.M, QP, g.nb, Csum, zt.Zc, o.dz3);
+  hipLaunchKernelGGL(psi2_pairblk_sym_kernel, dim3((g.M * g.M + 255) / 256), dim3(256), 0, s, g.M, g.nb, g.rem, p2sum, o.psi2);
+  hipLaunchKernelGGL(psi2_pairblk_dz3_kernel, dim3((g.M * QP + 255) / 256), dim3(256), 0, s, g.M, QP, g.nb, g.rem, Csum, zt.Zc, o.dz3);
   o.V2 = V2; o.T = T;
   return hipGetLastError();
 }

@@ -2,7 +2,7 @@
 16 x 16 blocks of inducing rows, entered from the blocked layer step and the unit entry point) against the oracle and against
 the blocked sweep kernels.
 
-`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (padded Q <= 48; the default picks it from 4096 rows), so the
+`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (padded Q <= 48; the default picks it from 2048 rows), so the
 small shapes of test_gpu_big can be run through it.  Tolerances as there: unit gradients 1e-10 of the largest entry, ELBO 1e-11,
 model gradients 1e-8."""
 import numpy as np
