@@ -71,9 +71,11 @@ static __device__ __forceinline__ double exp_tab_n(double x, const double* __res
   return ldexp(fma(tj, q, tj), n >> 8);
 }
 
-// pair p -> (a, b) on the circular diagonals
+// pair p -> (a, b) on the circular diagonals.  The slots behind the last pair (their weights are zero) stand for diagonal pairs
+// (a, a) with 16 different a per tile: all on one inducing row they would send every lane's h' read and V2 add of the tile to
+// one LDS address, and the workgroups of the last pair group, 16-way serialised there, took 20 % longer than all others.
 static __device__ __forceinline__ void pair_ab(int p, int M, int P, int& a, int& b) {
-  if (p >= P) { a = 0; b = 0; return; }
+  if (p >= P) { a = p % M; b = a; return; }
   const int d = p / M;
   a = p - d * M;
   b = a + d;
@@ -1150,6 +1152,23 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
     (void)hipMemcpy(hb, dbg_s, sizeof(hb), hipMemcpyDeviceToHost);
     const int nwg = g.G * g.RR;
     fprintf(stderr, "pair QP=%d core clock during the step loop of workgroup 0: %.0f MHz\n", QP, 100.0 * hb[13] / (hb[14] > 0 ? hb[14] : 1));
+    {                                             // spread of the workgroups' step loops: wall time (100 MHz ticks) and cycles, wave 0 of each
+      double wmin = 1e30, wmax = 0, wsum = 0, cmin = 1e30, cmax = 0;
+      for (int wg = 0; wg < nwg; ++wg) {
+        const double w = hb[(wg * 8) * 16 + 14], c = hb[(wg * 8) * 16 + 13];
+        wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax; wsum += w; cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+      }
+      fprintf(stderr, "pair QP=%d step loop per workgroup: wall min %.1f avg %.1f max %.1f us; cycles min %.0f max %.0f\n", QP, wmin / 100, wsum / nwg / 100,
+              wmax / 100, cmin, cmax);
+      fprintf(stderr, "  wall us by workgroup:");
+      for (int wg = 0; wg < nwg; ++wg) fprintf(stderr, " %.0f", hb[(wg * 8) * 16 + 14] / 100);
+      fprintf(stderr, "\n");
+      for (int x = 0; x < 8; ++x) {               // by XCD (workgroup i runs on XCD i mod 8)
+        double ws = 0, cs = 0; int n = 0;
+        for (int wg = x; wg < nwg; wg += 8) { ws += hb[(wg * 8) * 16 + 14]; cs += hb[(wg * 8) * 16 + 13]; ++n; }
+        fprintf(stderr, "  XCD %d: wall %.1f us, %.0f MHz\n", x, ws / n / 100, 100.0 * cs / ws);
+      }
+    }
     for (int role = 0; role < 2; ++role) {
       double acc[16] = {0};
       for (int wg = 0; wg < nwg; ++wg) for (int w = 4 * role; w < 4 * role + 4; ++w) for (int i = 0; i < 13; ++i)
