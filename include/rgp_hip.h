@@ -117,14 +117,15 @@ rgp_status rgp_get_profile(rgp_handle h, double* psi2_ms, int64_t* psi2_launches
 rgp_status rgp_set_deterministic(rgp_handle h, int on);
 
 /* Which kernels run the fused psi2 pass of the SVI bound (kern.psi2 + its gradients, svi_vardtc.py:48-50, layers.py:98-132,
- * 1452-1458) for M <= 112, Q <= 64.  mode 0: the sweep kernels on the vector pipe (one thread per (data row, inducing row));
+ * 1452-1458) for M <= 112, Q <= 64, and the psi2 term of the blocked layer step for 112 < M <= 1024, padded Q <= 48.
+ * mode 0: the sweep kernels on the vector pipe (one thread per (data row, inducing row));
  * 1: the pair form on the fp64 matrix pipe (exponent, exponential and both back products once per UNORDERED pair of inducing
- * rows) where it pays (M >= 48 and >= 12288 data rows), the sweep kernels elsewhere; 2: the pair form wherever its LDS image
- * fits; -1 (default): the environment variable RGP_PSI2_PAIR if set, else 1.  rgp_set_deterministic(1) always selects the
- * fixed-order sweep kernel.  Results agree to rounding between the modes. */
+ * rows) where it pays (48 <= M <= 112 from 12288 data rows, M > 128 from 2048 data rows), the sweep kernels elsewhere; 2: the
+ * pair form wherever its LDS image fits; -1 (default): the environment variable RGP_PSI2_PAIR if set, else 1.
+ * rgp_set_deterministic(1) always selects the fixed-order sweep kernels.  Results agree to rounding between the modes. */
 rgp_status rgp_set_psi2_pair(rgp_handle h, int mode);
-/* 1 if the fused psi2 pass of an SVI layer step with N data rows, M inducing points and Q window columns would run in the pair
- * form under the handle's current mode, 0 if in the sweep kernels (a query for benchmarks and logs; no reference counterpart). */
+/* 1 if the psi2 term of an SVI layer step with N data rows, M inducing points and Q window columns would run in the pair form
+ * under the handle's current mode, 0 if in the sweep kernels (a query for benchmarks and logs; no reference counterpart). */
 int        rgp_psi2_pair_would_run(rgp_handle h, int64_t N, int M, int Q);
 
 /* The library overlaps the M x M algebra and the row preparation with the psi passes on three streams of its own.  HIP maps
