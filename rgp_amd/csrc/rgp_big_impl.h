@@ -312,7 +312,127 @@ __global__ void __launch_bounds__(256) big_psi1_fwd_kernel(const int64_t N, cons
   }
 }
 
-static void launch_big_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* P, double* H) {
+// The same two arrays on the matrix pipe: per tile of 16 data rows and 16 inducing rows, two [16 x 2 QP] x [2 QP x 16] products
+//   psi1 exponent = g1 + (e mu) Z^T + (2 e) (-Z^2 / 4)^T,      h = (d2 mu) Z^T + d2 (-Z^2 / 4)^T - 1/4 sum_q lam z^2
+// (v_mfma_f64_16x16x4; wave = one tile of rows, left operands straight from global memory, right operands from LDS images of Z
+// and -Z^2 / 4 for a chunk of up to 112 inducing rows = blockIdx.y).  h can also be written as the pair form's record wants it
+// (Hq [row tile][block of 16 inducing rows][16][16] = h + g0 / 2, -inf for rows beyond N, 0 for columns beyond M).
+#define BP1_MT 7              // tiles of 16 inducing rows per chunk: 2 x 112 x (QP + 1) doubles of LDS, two workgroups per CU
+typedef double bp1_d4 __attribute__((ext_vector_type(4)));
+template <int QP>
+__global__ void __launch_bounds__(256, 2) big_psi1_fwd_mfma_kernel(const int64_t N, const int64_t ntiles, const int M, const int nb,
+                                                                    const double* __restrict__ Zc, const double* __restrict__ lam,
+                                                                    const double* __restrict__ e1, const double* __restrict__ em,
+                                                                    const double* __restrict__ d2, const double* __restrict__ Xmu,
+                                                                    const double* __restrict__ g1, const double* __restrict__ g0,
+                                                                    double* __restrict__ P, double* __restrict__ H,
+                                                                    double* __restrict__ Hq) {
+  constexpr int ZQ = QP + 1, KQ = QP / 4;
+  extern __shared__ double bp1_sm[];
+  const int mt0 = blockIdx.y * BP1_MT;
+  const int nmt = (nb - mt0 < BP1_MT) ? nb - mt0 : BP1_MT;
+  double* const Zs = bp1_sm;                      // [16 BP1_MT][ZQ]   z
+  double* const Z2s = Zs + 16 * BP1_MT * ZQ;      // [16 BP1_MT][ZQ]   -z^2 / 4
+  double* const el = Z2s + 16 * BP1_MT * ZQ;      // [16 BP1_MT]       1/4 sum_q lam z^2
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int i = t; i < 16 * nmt * ZQ; i += 256) {
+    const int ml = i / ZQ, q = i - ml * ZQ, m = 16 * mt0 + ml;
+    const double z = (m < M && q < QP) ? Zc[(size_t)m * QP + q] : 0.0;
+    Zs[i] = z;
+    Z2s[i] = -0.25 * z * z;
+  }
+  __syncthreads();
+  for (int ml = t; ml < 16 * nmt; ml += 256) {
+    double e = 0.0;
+    for (int q = 0; q < QP; ++q) e -= lam[q] * Z2s[ml * ZQ + q];
+    el[ml] = e;
+  }
+  __syncthreads();
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + w; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t n0 = tile * 16, n = n0 + c;
+    const bool ok = n < N;
+    const size_t o = (size_t)(ok ? n : N - 1) * QP + g;
+    double Adm[KQ], Ad[KQ], Aem[KQ], Ae[KQ];
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) {
+      const double dv = ok ? d2[o + 4 * kk] : 0.0, ev = ok ? e1[o + 4 * kk] : 0.0;
+      Ad[kk] = dv;
+      Adm[kk] = dv * Xmu[o + 4 * kk];
+      Ae[kk] = 2.0 * ev;
+      Aem[kk] = ok ? em[o + 4 * kk] : 0.0;
+    }
+    double g1r[4], g0h[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t nr = n0 + 4 * rr + g;
+      g1r[rr] = (P && nr < N) ? g1[nr] : 0.0;
+      g0h[rr] = (nr < N) ? (Hq ? 0.5 * g0[nr] : 0.0) : -INFINITY;
+    }
+    for (int mt = 0; mt < nmt; ++mt) {
+      bp1_d4 aH = (bp1_d4){0.0, 0.0, 0.0, 0.0}, aP = (bp1_d4){0.0, 0.0, 0.0, 0.0};
+      const int zo = (16 * mt + c) * ZQ + g;
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        const double zs = Zs[zo + 4 * kk], z2 = Z2s[zo + 4 * kk];
+        if (H || Hq) {
+          aH = __builtin_amdgcn_mfma_f64_16x16x4f64(Adm[kk], zs, aH, 0, 0, 0);
+          aH = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[kk], z2, aH, 0, 0, 0);
+        }
+        if (P) {
+          aP = __builtin_amdgcn_mfma_f64_16x16x4f64(Aem[kk], zs, aP, 0, 0, 0);
+          aP = __builtin_amdgcn_mfma_f64_16x16x4f64(Ae[kk], z2, aP, 0, 0, 0);
+        }
+      }
+      const int m = 16 * (mt0 + mt) + c;
+      const double elm = el[16 * mt + c];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int64_t nr = n0 + 4 * rr + g;
+        const double h = aH[rr] - elm;
+        if (nr < N && m < M) {
+          if (P) P[(size_t)nr * M + m] = exp(g1r[rr] + aP[rr]);
+          if (H) H[(size_t)nr * M + m] = h;
+        }
+        if (Hq) Hq[(((size_t)tile * nb + mt0 + mt) * 16 + 4 * rr + g) * 16 + c] = (nr < N) ? ((m < M) ? h + g0h[rr] : 0.0) : -INFINITY;
+      }
+    }
+  }
+}
+
+template <int QP>
+static hipError_t bp1_launch(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* P, double* H, double* Hq,
+                             int num_cu) {
+  const int nb = (M + 15) / 16, nch = (nb + BP1_MT - 1) / BP1_MT;
+  const int64_t ntiles = (N + 15) / 16;
+  const size_t lds = (2 * (size_t)16 * BP1_MT * (QP + 1) + 16 * BP1_MT) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute((const void*)big_psi1_fwd_mfma_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int64_t gx = (2 * (int64_t)(num_cu > 0 ? num_cu : 256) + nch - 1) / nch;       // about two workgroups per CU in all
+  if (gx > (ntiles + 3) / 4) gx = (ntiles + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((big_psi1_fwd_mfma_kernel<QP>), dim3((unsigned)gx, (unsigned)nch), dim3(256), lds, s, N, ntiles, M, nb, zt.Zc, zt.lam,
+                     rt.e1, rt.em, rt.d2, rt.Xmu, rt.g1, rt.g0, P, H, Hq);
+  return hipSuccess;
+}
+
+// psi1 (P, may be null), h (H, row-major, may be null) and / or h in the pair form's block layout (Hq, may be null).
+// RGP_PSI1_FWD_MFMA=0 in the environment keeps the vector-pipe kernel (which cannot write Hq).
+static bool big_psi1_fwd_on_matrix_pipe() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RGP_PSI1_FWD_MFMA"); v = e ? (atoi(e) != 0) : 1; }
+  return v != 0;
+}
+static void launch_big_psi1_fwd(hipStream_t s, int64_t N, int M, const ZTerms& zt, const RowTerms& rt, double* P, double* H,
+                                double* Hq = nullptr, int num_cu = 0) {
+  if (Hq || big_psi1_fwd_on_matrix_pipe()) {
+    switch (zt.QP) {
+#define B1M(qp) case qp: (void)bp1_launch<qp>(s, N, M, zt, rt, P, H, Hq, num_cu); return;
+      B1M(8) B1M(16) B1M(20) B1M(24) B1M(32) B1M(40) B1M(48) B1M(56) B1M(64)
+#undef B1M
+      default: break;
+    }
+  }
   const dim3 grid((unsigned)(N < 4096 ? N : 4096), (unsigned)((M + 255) / 256));
   switch (zt.QP) {
 #define B1F(qp) case qp: hipLaunchKernelGGL((big_psi1_fwd_kernel<qp>), grid, dim3(256), 0, s, N, M, zt.Zc, zt.lam, rt.e1, rt.em, rt.d2, rt.Xmu, rt.g1, P, H); break;
@@ -930,11 +1050,11 @@ static rgp_status big_psi2_forward(rgp_handle h, hipStream_t s, const BigPlan& p
 // rgp_wideq_impl.h):  [a1 | vz2 | w] = v [Z | Z^2 | 1],  B1 = v^T (d2 o mu),  B2 = v^T d2,  dZ2 = 2 B1 - Z o B2 - dZ3 and the row
 // gradients.  Outputs as launch_big_psi2_fwd + launch_big_psi2_bwd: L.psi2, row gradients added to L.gmu / L.gS, L.dz2, L.dlam2,
 // L.wsum2.
-static rgp_status bp_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, BigWs& L) {
+static rgp_status bp_psi2(rgp_handle h, hipStream_t s, const BigPlan& p, int64_t N, int M, int Q, BigWs& L, bool hq_ready) {
   const int QP = p.QP;
   PairBlkOut o{};
   o.psi2 = L.psi2; o.dz3 = L.pb_dz3;
-  rgp_status st = launch_psi2_pairblk(h, s, p.pbg, N, L.zt, L.rt, L.H, L.dLs, L.pb_ws, o);
+  rgp_status st = launch_psi2_pairblk(h, s, p.pbg, N, L.zt, L.rt, hq_ready ? nullptr : L.H, L.dLs, L.pb_ws, o);
   if (st) return st;
   hipLaunchKernelGGL(wq_dmu_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, L.rt.d2, L.rt.Xmu, L.pb_DM);
   {
@@ -1025,7 +1145,9 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
   launch_rowprep_dense(s, N, Q, mu, S, variance, L.zt, L.rt);
   hipLaunchKernelGGL(big_zz_kernel, dim3(big_nb256((int64_t)M * p.W)), dim3(256), 0, s, M, QP, p.W, L.zt.Zc, L.ZZ);
   if (L.wide) wq_psi1_fwd(s, p, N, M, L, L.wq);
-  else launch_big_psi1_fwd(s, N, M, L.zt, L.rt, dL_dpsi1 ? L.P : nullptr, dL_dpsi2 ? L.H : nullptr);
+  const bool hq = !L.wide && p.pb && dL_dpsi2 && big_psi1_fwd_on_matrix_pipe();    // h goes straight into the pair form's block layout
+  if (!L.wide) launch_big_psi1_fwd(s, N, M, L.zt, L.rt, dL_dpsi1 ? L.P : nullptr, (dL_dpsi2 && !hq) ? L.H : nullptr,
+                                   hq ? psi2_pairblk_hq(p.pbg, L.pb_ws) : nullptr, p.num_cu);
   if (dL_dpsi1) {
     hipLaunchKernelGGL(big_mul_kernel, dim3(big_nb256(N * M)), dim3(256), 0, s, N * M, dL_dpsi1, L.P, L.Lp);
     launch_big_psi1_bwd(s, p, N, M, Q, L.zt, L.rt, L);
@@ -1037,7 +1159,7 @@ static rgp_status big_psi_backward(rgp_handle h, int64_t N, int M, int Q, const 
     hipLaunchKernelGGL(symmetrise_kernel, dim3(big_nb256((int64_t)M * M)), dim3(256), 0, s, M, dL_dpsi2, L.dLs);
     hipLaunchKernelGGL(big_dm_kernel, dim3(big_nb256(N * QP)), dim3(256), 0, s, N * QP, QP, L.rt.d2, L.zt.lam, L.dm);
     if (L.wide) st = wq_psi2(h, s, p, N, M, Q, L, L.wq);
-    else if (p.pb) st = bp_psi2(h, s, p, N, M, Q, L);
+    else if (p.pb) st = bp_psi2(h, s, p, N, M, Q, L, hq);
     else if (!(st = big_psi2_forward(h, s, p, N, M, L, L.psi2)))
       st = launch_big_psi2_bwd(h, s, p, N, M, Q, L.zt, L.rt, L.dLs, L.H, L, 1);
     if (st) return st;
@@ -1106,10 +1228,11 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
     hipLaunchKernelGGL(wq_scal_kernel, dim3(1), dim3(64), 0, s, in->noise, D, c.scal);
 
   // psi1 side
+  const bool hq = !L.wide && p.pb && big_psi1_fwd_on_matrix_pipe();      // h goes straight into the pair form's block layout
   if (L.wide)
     wq_psi1_fwd(s, p, N, M, L, L.wq);
   else
-    launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, L.H);
+    launch_big_psi1_fwd(s, N, M, L.zt, L.rt, L.P, hq ? nullptr : L.H, hq ? psi2_pairblk_hq(p.pbg, L.pb_ws) : nullptr, p.num_cu);
   {                                                          // Lp = psi1 o (Ym Cpsi1^T)              (svi_vardtc.py:164-167)
     GemmArgs g;
     g.m = (int)N; g.n = M; g.k = D; g.A = L.Ym; g.lda = D; g.B = c.Cpsi1; g.ldb = D; g.tb = 1; g.C = L.Lp; g.ldc = M;
@@ -1138,7 +1261,7 @@ static rgp_status big_svi_layer_step(rgp_handle h, const rgp_layer_in* in, const
     prof_end(h);
   } else if (p.pb) {
     prof_begin(h, (double)N * M * M * Q);                     // rgp_get_profile times the whole fused psi2 term
-    st = bp_psi2(h, s, p, N, M, Q, L);
+    st = bp_psi2(h, s, p, N, M, Q, L, hq);
     prof_end(h);
   } else {
     st = big_psi2_forward(h, s, p, N, M, L, L.psi2);

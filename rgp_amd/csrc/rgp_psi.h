@@ -144,6 +144,9 @@ struct PairBlkOut {
 bool psi2_pairblk_geom(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g);
 bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, PairBlkGeom& g);
 size_t psi2_pairblk_ws_doubles(const PairBlkGeom& g, int64_t N);
+// where the h blocks [row tile][block of 16 inducing rows][16][16] (= h + g0 / 2; -inf beyond N, 0 beyond M) live inside the
+// workspace: a caller that fills them itself passes H = nullptr to launch_psi2_pairblk
+double* psi2_pairblk_hq(const PairBlkGeom& g, double* ws);
 rgp_status launch_psi2_pairblk(rgp_handle h, hipStream_t s, const PairBlkGeom& g, int64_t N, const ZTerms& zt, const RowTerms& rt,
                                const double* H, const double* dLs, double* ws, PairBlkOut& out);
 // out[i] = scale * sum_g part[g*stride + i], i < len (fixed order)

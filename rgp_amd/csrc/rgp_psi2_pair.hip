@@ -1239,8 +1239,8 @@ static __host__ __device__ inline int pairblk_slot(int a, int b, int nb, int rem
 
 // Records of the blocked form, one per tile of 16 data rows: rec [tile][ND2 x 128] = -d2 / 2 as [16][TS], zero padded;
 // Hq [tile][column block][16 rows][16] = h[n,m] + g0[n] / 2 (h: the (row, m) part of the exponent as the blocked psi1 forward pass
-// leaves it, [N][M]); rows beyond N get -inf (their exponentials are 0), columns beyond M get 0.  Also zeroes every array the main
-// kernel adds into.
+// leaves it, [N][M]; nullptr if that pass has written Hq itself); rows beyond N get -inf (their exponentials are 0), columns
+// beyond M get 0.  Also zeroes every array the main kernel adds into.
 template <int QP>
 __global__ void __launch_bounds__(256) psi2_pairblk_prep_kernel(const int64_t N, const int64_t ntiles, const int M, const int nb,
                                                                  const int Mld, const double* __restrict__ d2,
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(256) psi2_pairblk_prep_kernel(const int64_t N,
       r[i] = (row < 16 && col < QP && n < N) ? -0.5 * d2[(size_t)n * QP + col] : 0.0;
     }
     double* const hq = Hq + (size_t)tile * nb * 256;
-    for (int i = t; i < nb * 256; i += 256) {
+    if (H) for (int i = t; i < nb * 256; i += 256) {           // (H == nullptr: the psi1 forward pass has written the blocks itself)
       const int blk = i >> 8, row = (i >> 4) & 15, m = 16 * blk + (i & 15);
       const int64_t n = n0 + row;
       hq[i] = (n < N) ? ((m < M) ? H[(size_t)n * M + m] + 0.5 * g0[n] : 0.0) : -INFINITY;
@@ -1368,6 +1368,7 @@ bool psi2_pairblk_selected(rgp_handle h, int64_t N, int M, int QP, int Mld, Pair
 }
 
 static inline size_t pb_r(size_t n) { return (n + 31) & ~(size_t)31; }
+double* psi2_pairblk_hq(const PairBlkGeom& g, double* ws) { return ws + pb_r((size_t)g.ntiles * g.ND2 * 128); }
 size_t psi2_pairblk_ws_doubles(const PairBlkGeom& g, int64_t N) {
   return pb_r((size_t)g.ntiles * g.ND2 * 128) + pb_r((size_t)g.ntiles * g.nb * 256) + pb_r((size_t)N * g.Mld) + pb_r((size_t)N * g.QP) +
          pb_r((size_t)g.G * g.TG * 16 * g.QP) + pb_r((size_t)g.G * g.TG * 16) + 64;
