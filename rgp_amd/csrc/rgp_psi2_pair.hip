@@ -841,13 +841,15 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_prep_kernel(const int64_t N,
 // super-tile are staged in LDS.
 //   job B  (wave w owns the inducing-row tiles w and w + 4): [B1 | B2] += v^T (d2 mu | d2), accumulated in registers over all
 //           the workgroup's super-tiles; at the end the slab dz[q][m] = 2 B1 - z B2.
-//   job A  (wave = (tile of 16 rows, Z or Z^2)): a1 = v Z or vz2 = v Z^2, right operands from global memory (Z is small
-//           and cached), the row sums of v on the way; the results go to LDS over the (d2 mu | d2) image.
+//   job A  (wave = (tile of 16 rows, Z or Z^2)): a1 = v Z or vz2 = v Z^2, right operands from an LDS image of the first 4 KL
+//           rows of Z -- as many as fit next to the tiles with two workgroups per CU -- and from global memory for the rest
+//           (with all of them from global memory a quarter of the kernel's time was the wait for those loads), the row sums
+//           of v on the way; the results go to LDS over the (d2 mu | d2) image.
 //   epilogue (thread = (window column, every RPP-th row)): the row gradients from a1, vz2, T and the row sums, dinv_l and
 //           sum-of-weights partials.
 // ------------------------------------------------------------------------------------------------------------------
 template <int QP>
-__global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N, const int M, const int Q, const int PW, const int M2,
+__global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N, const int M, const int Q, const int PW, const int M2, const int KL,
                                                                  const double* __restrict__ PV, const double* __restrict__ Zc,
                                                                  const double* __restrict__ lam, const double* __restrict__ Xmu,
                                                                  const double* __restrict__ d2, double* __restrict__ gmu,
@@ -860,10 +862,16 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N,
   double* const vS = sm;                          // [32][VS]  v = V2 / 2, zero beyond M and beyond N
   double* const dS = vS + 32 * VS;                // [32][DS]  (d2 mu | d2), each half padded to 16 QT; later (a1 | vz2)
   double* const wsS = dS + 32 * DS;               // [32]      row sums of v
+  constexpr int ZQ = QP + 1;
+  double* const Zl = wsS + 32;                    // [4 KL][ZQ]  the first 4 KL rows of Z
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4, c = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t nst = (N + 31) >> 5;
   const bool two = w + 4 < MT;                    // this wave owns a second tile of inducing rows
+  for (int i = t; i < 4 * KL * ZQ; i += 256) {    // (the first barrier of the loop over the super-tiles orders these writes)
+    const int m = i / ZQ, q = i - m * ZQ;
+    Zl[i] = (m < M && q < QP) ? Zc[(size_t)m * QP + q] : 0.0;
+  }
   d4 Bacc[2][CT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -944,8 +952,19 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N,
     double wsum = 0.0;
     {
       const double* vr = vS + (16 * rt + c) * VS + g;
+      const double* zl = Zl + g * ZQ + c;
 #pragma unroll 2
-      for (int kk = 0; kk < K4; ++kk) {
+      for (int kk = 0; kk < KL; ++kk) {
+        const double a = vr[4 * kk];
+        wsum += a;
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+          const double z = (16 * j + c < QP) ? zl[4 * kk * ZQ + 16 * j] : 0.0;
+          Aacc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ch ? z * z : z, Aacc[j], 0, 0, 0);
+        }
+      }
+#pragma unroll 2
+      for (int kk = KL; kk < K4; ++kk) {
         const double a = vr[4 * kk];
         wsum += a;
         const int m = 4 * kk + g;
@@ -982,7 +1001,7 @@ __global__ void __launch_bounds__(256, 2) psi2_pair_rows_kernel(const int64_t N,
           const double dmu = 2.0 * dq * (a1 - mu * ws);
           const double ddq = -mu * mu * ws + 2.0 * mu * a1 - a23 + 0.5 * ws / dq;
           const double dSv = -2.0 * dq * dq * ddq;
-          if (accumulate) { gmu[o] += dmu; gS[o] += dSv; }
+          if (accumulate) { atomicAdd(&gmu[o], dmu); atomicAdd(&gS[o], dSv); }      // (no return value: nothing waits for the old sums)
           else { gmu[o] = dmu; gS[o] = dSv; }
           dl_acc += ddq * (dq * il) * (dq * il) - 0.5 * ws * il;
           if (eq == 0) ws_acc += ws;
@@ -1179,10 +1198,14 @@ static hipError_t pair_launch(hipStream_t s, const PairGeom& g, int64_t N, int Q
   }
 #endif
   // row gradients, dinv_l / weight-sum partials, B slabs
-  const size_t lr = (32 * (size_t)(16 * MT + 1) + 32 * (size_t)(32 * ((QP + 15) / 16) + 1) + 32) * sizeof(double);
+  const size_t lr0 = (32 * (size_t)(16 * MT + 1) + 32 * (size_t)(32 * ((QP + 15) / 16) + 1) + 32) * sizeof(double);
+  int KL = (int)((80 * 1024 - lr0) / (4 * (QP + 1) * sizeof(double)));       // k-steps of job A whose rows of Z fit: two workgroups per CU
+  if (KL > (M + 3) / 4) KL = (M + 3) / 4;
+  if (KL < 0) KL = 0;
+  const size_t lr = lr0 + (size_t)4 * KL * (QP + 1) * sizeof(double);
   e = hipFuncSetAttribute((const void*)psi2_pair_rows_kernel<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, M, Q, g.PW, g.M2, PV, zt.Zc, zt.lam, rt.Xmu, rt.d2,
+  hipLaunchKernelGGL((psi2_pair_rows_kernel<QP>), dim3(g.NB), dim3(256), lr, s, N, M, Q, g.PW, g.M2, KL, PV, zt.Zc, zt.lam, rt.Xmu, rt.d2,
                      o.gmu, o.gS, o.accumulate, o.dz_part, o.dlam_part, o.wsum_part);
   // dZ3 from the C partials: one more slab behind the row kernel's
   launch_reduce(s, g.RR, (int64_t)g.Ppad * QP, (int64_t)g.Ppad * QP, Cpart, Csum, 1.0, 0);
