@@ -162,6 +162,7 @@ def main():
     for k in range(steps):
         e = step(warmup + k)
         marks[k + 1].record()
+    t_enq = time.perf_counter() - t0       # host time to enqueue all steps (the device is still running unless the host is the limit)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -249,6 +250,7 @@ def main():
                        'parallelism': 'dp%d (sequences sharded; %d doubles of global gradients + ELBO all-reduced per step, %s)'
                                       % (world, m.n_global + 1, 'ONE bucket' if (a.bucket == 'single' or nl > 3) else 'one collective per layer')},
             'elbo_last_step': elbo,
+            'host_enqueue_ms_per_step': 1e3 * t_enq / steps,
             'step_ms_main_stream': {'median': float(np.median(step_ms)), 'p10': float(np.percentile(step_ms, 10)),
                                     'p90': float(np.percentile(step_ms, 90)),
                                     'note': 'HIP events on the main stream between consecutive steps (rank 0); value uses the wall clock over all steps'},
