@@ -27,7 +27,8 @@ def HP():
 # M = 500 (the last block has 4 rows), three sweep blocks (600); ragged last tile of 16 data rows; Q = 20 takes five pair tiles per
 # wave, Q = 17 and 6 are padded, Q = 48 is the widest window whose LDS image fits; Q = 57 (padded 64) falls back to the sweeps
 SHAPES = [(70, 129, 8, 2), (150, 256, 40, 20), (90, 500, 40, 20), (33, 600, 20, 0), (257, 130, 17, 0), (40, 300, 48, 3),
-          (19, 145, 6, 0), (40, 300, 57, 3)]
+          (19, 145, 6, 0), (40, 300, 57, 3),
+          (24, 1024, 20, 0), (50, 513, 12, 2)]     # the largest M (64 column blocks); a last block of ONE inducing row
 
 
 @pytest.mark.parametrize('N,M,Q,nctrl', SHAPES)
@@ -94,3 +95,19 @@ def test_model_through_the_blocked_pair_form(cfg):
     g.handle.set_psi2_pair(2)
     assert g.handle.psi2_pair_would_run(64, cfg['M'], 40)
     compare(o, g, rtol=1e-8)
+
+
+def test_would_run_query_and_fallbacks(HP):
+    """rgp_psi2_pair_would_run for the blocked layer step: mode 2 wherever the LDS image fits (padded Q <= 48), mode 1 from 2048
+    rows, never in the deterministic mode."""
+    H = HP
+    assert H.psi2_pair_would_run(64, 500, 40) and H.psi2_pair_would_run(64, 1024, 20)
+    assert not H.psi2_pair_would_run(64, 500, 57)            # padded to 64 columns: the LDS image does not fit
+    H.set_psi2_pair(1)
+    assert not H.psi2_pair_would_run(2047, 500, 40) and H.psi2_pair_would_run(2048, 500, 40)
+    H.set_psi2_pair(0)
+    assert not H.psi2_pair_would_run(100000, 500, 40)
+    H.set_psi2_pair(2)
+    H.set_deterministic(True)
+    assert not H.psi2_pair_would_run(100000, 500, 40)
+    H.set_deterministic(False)
