@@ -27,6 +27,8 @@
 // leaves the chip once per step as this pair group's partial.  The partials of the G pair groups are summed by the row kernel.
 // Pair order: circular diagonals p = d M + a, b = (a + d) mod M, d = 0 .. M/2: every unordered pair once, no padding inside the
 // list, and the 16 pairs of a tile touch 16 different a and 16 different b (conflict-free h reads and V2 adds).
+// For M > 112 (the blocked layer step) the same body runs on pair groups over 16 x 16 blocks of inducing rows and on local row
+// indices (template flag BLK; see "Blocked form" at the end of the file).
 #include "rgp_psi.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(512, 2) psi2_pair_kernel(const PairArgs a) {
 template <int QP>
 __global__ void __launch_bounds__(512, 2) psi2_pairblk_kernel(const PairArgs a) {
   for (int task = blockIdx.x; task < a.ntasks; task += gridDim.x) {
-    const int gi = task % a.G, rr = task / a.G;
+    const int gi = task % a.G, rr = task / a.G;       // (row range fastest instead: 1341 against 1332 ms per config-5 step)
     if (threadIdx.x < 256) psi2_pair_body<QP, pair_nt(QP), false, true>(a, gi, rr);
     else psi2_pair_body<QP, pair_nt(QP), true, true>(a, gi, rr);
     __syncthreads();                              // the next task's set-up overwrites the tables and tiles
