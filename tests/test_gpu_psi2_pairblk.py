@@ -111,3 +111,19 @@ def test_would_run_query_and_fallbacks(HP):
     H.set_deterministic(True)
     assert not H.psi2_pair_would_run(100000, 500, 40)
     H.set_deterministic(False)
+
+
+def test_nan_input_reaches_the_gradients(HP):
+    """A NaN in one window mean is not dropped by the exponential's clamp: the gradients of that row and the sums over the
+    rows come out NaN, the other rows' gradients stay finite."""
+    H = HP
+    N, M, Q = 40, 130, 8
+    mu, S, Z, var, il = make(N, M, Q, 3)
+    mu[7, 2] = np.nan
+    w2 = np.random.default_rng(1).standard_normal((M, M))
+    g = H.psi_backward(dev(H, mu), dev(H, S), dev(H, Z), dev(H, [var]), dev(H, il), 0.0, None, dev(H, w2))
+    H.sync()
+    assert np.isnan(g['dmu'].cpu().numpy()[7]).all()
+    assert np.isnan(g['dZ'].cpu().numpy()).any()
+    rest = np.delete(g['dmu'].cpu().numpy(), 7, axis=0)
+    assert np.isfinite(rest).all()
