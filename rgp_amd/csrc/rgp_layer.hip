@@ -1254,9 +1254,18 @@ static rgp_status svi_prepare_slot(rgp_handle h, const rgp_layer_in* in, int mod
     if ((st = rgp_ensure_ws_slot(h, slot, need))) return st;
   }
   hipStream_t s_pre = h->overlap ? h->side_pre : h->stream;
-  // everything below is off the main stream: row work on side_rows; a chain-only prepare keeps off that stream too, because
-  // it waits for the side_post stream and would hold back the next step's row work queued behind it
-  hipStream_t s = h->overlap ? (mode == 1 ? h->side_pre : h->side_rows) : h->stream;
+  // Chain-only prepares of consecutive slots (= consecutive layers) alternate between the chain stream and the row stream:
+  // a layer's chain is 0.6 ms of dependent one-workgroup kernels (M = 100), and with all layers' chains behind each other on
+  // one stream that stream alone set a floor of 2.2 ms per step for short steps (1 - 4 sequences), while the row stream's own
+  // work is tens of microseconds there.  (The row work queued behind such a chain waits for it; it is the row work of a later
+  // step.)  Only for short steps: measured at M = 100 (steps/s, one stream : alternating) 16 304 rows 413 : 442, 8 152 rows
+  // 464 : 533, 4 076 rows 462 : 609, but 32 608 rows 267 : 263 and 130 432 rows 77.4 : 74.3 -- there the row work is long and
+  // must not wait behind a chain.  RGP_CHAIN_ALT=0 keeps every chain on the chain stream, 2 alternates at every size.
+  static int chain_alt = -1;
+  if (chain_alt < 0) { const char* e = getenv("RGP_CHAIN_ALT"); chain_alt = e ? atoi(e) : 1; }
+  if (h->overlap && mode == 1 && (slot & 1) && (chain_alt >= 2 || (chain_alt == 1 && N <= 20000))) s_pre = h->side_rows;
+  // everything below is off the main stream: row work on side_rows, a chain-only prepare on its chain stream
+  hipStream_t s = h->overlap ? (mode == 1 ? s_pre : h->side_rows) : h->stream;
   if (h->overlap) {
     if (mode == 1) {
       // the parameters were updated on the side_post stream (rgp_adam_step_post); the slot's previous users are covered
