@@ -120,7 +120,7 @@ rgp_status rgp_set_deterministic(rgp_handle h, int on);
  * 1452-1458) for M <= 112, Q <= 64, and the psi2 term of the blocked layer step for 112 < M <= 1024, padded Q <= 48.
  * mode 0: the sweep kernels on the vector pipe (one thread per (data row, inducing row));
  * 1: the pair form on the fp64 matrix pipe (exponent, exponential and both back products once per UNORDERED pair of inducing
- * rows) where it pays (48 <= M <= 112 from 12288 data rows, M > 128 from 2048 data rows), the sweep kernels elsewhere; 2: the
+ * rows) where it pays (48 <= M <= 112 from 4000 data rows, M > 128 from 2048 data rows), the sweep kernels elsewhere; 2: the
  * pair form wherever its LDS image fits; -1 (default): the environment variable RGP_PSI2_PAIR if set, else 1.
  * rgp_set_deterministic(1) always selects the fixed-order sweep kernels.  Results agree to rounding between the modes. */
 rgp_status rgp_set_psi2_pair(rgp_handle h, int mode);

@@ -1118,7 +1118,8 @@ bool psi2_pair_geom(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
 
 // The pair form pays once a workgroup's 512 or 640 pairs are mostly real and every workgroup has a few dozen steps of 16 rows to walk.
 // Measured against the sweep kernels at M = 100, Q = 40 / 40 / 20 (steps/s of the whole SVI step, pair : sweep):
-// 130432 rows 66.0 : 59.2, 65216 rows 128.9 : 109.7, 32608 rows 233 : 206, 16304 rows 395 : 370.  Smaller sizes were not measured.
+// 130432 rows 77.2 : 59.1, 65216 rows 145 : 110, 32608 rows 265 : 203, 16304 rows 441 : 364, 8152 rows 582 : 533,
+// 4076 rows 643 : 612.  Smaller sizes were not measured: the default takes the pair form from 4000 rows.
 bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   int mode = h->psi2_pair;
   if (mode < 0) {
@@ -1129,7 +1130,7 @@ bool psi2_pair_selected(rgp_handle h, int64_t N, int M, int QP, PairGeom& g) {
   if (mode <= 0 || h->deterministic) return false;
   if (!psi2_pair_geom(h, N, M, QP, g)) return false;
   if (mode >= 2) return true;
-  return M >= 48 && N >= 12288;
+  return M >= 48 && N >= 4000;
 }
 
 size_t psi2_pair_ws_doubles(const PairGeom& g, int64_t N) {

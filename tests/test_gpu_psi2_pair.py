@@ -1,6 +1,6 @@
 """The pair form of the fused psi2 pass (fp64 matrix pipe, rgp_amd/csrc/rgp_psi2_pair.hip) against the oracle.
 
-`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (the default picks it only for M >= 48 and >= 12288 rows), so the
+`Handle.set_psi2_pair(2)` forces it wherever its LDS image fits (the default picks it only for M >= 48 and >= 4000 rows), so the
 small shapes of the other tests can be run through it.  Tolerances as in test_gpu_kernels / test_gpu_model: gradients of the
 unit entry point 1e-10 of the largest entry, ELBO 1e-11, model gradients 1e-9."""
 import numpy as np
